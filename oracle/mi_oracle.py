@@ -1,0 +1,321 @@
+"""CPU oracle for the MI-critic hot path.  TEST INFRASTRUCTURE ONLY.
+
+This file is a CPU restatement (torch CPU / numpy, fp32 or fp64) of the reference algorithm for the one
+path this repository accelerates.  It is the *checker*: only ``tests/``, ``__graft_entry__.smoke()`` and
+the ``cpu_baseline`` leg of ``bench.py`` may import it.  Nothing under ``mutual-information-multimodal_amd/``
+imports it, and the product path raises when the HIP library is missing instead of falling back to it.
+
+Parity status: PINNED.  ``tests/golden/make_goldens.py`` runs the reference's own functions (in the build
+container only, where ``/root/reference`` exists) and commits their outputs as fixtures under
+``tests/golden/``; ``tests/test_oracle_golden.py`` checks every function below against those fixtures.
+The reference holds no golden vectors of its own.
+
+Reference code restated here (file:line relative to the reference root):
+
+* ``pair_index``        <- MultiModalManager.create_mi_pairs, mutual_info_img_txt/main_utils.py:80-110
+* ``create_mi_pairs``   <- same, main_utils.py:93 (positives) and :99-108 (negatives, gap-major / i-minor)
+* ``mlp_forward``       <- make_mlp, mutual_info_img_txt/model.py:18-32 (Linear/ReLU/Linear/ReLU/Linear)
+* ``dv_bound_loss``     <- mutual_info_img_txt/mi_critics.py:3-12
+* ``infonce_bound_loss``<- mutual_info_img_txt/mi_critics.py:14-23
+* ``literal_step``      <- the call site main_utils.py:220-226 (pairs -> critic -> bound -> backward)
+
+The factorised forms (``concat_scores_matrix``, ``bound_from_matrix``) use the identity
+``W1 [x_i ; y_j] + b1 = W1x x_i + (W1y y_j + b1)`` and are checked against the literal
+form in the tests.  ``bilinear_scores`` / ``separable_scores`` are extensions that have no reference code:
+their scorer parity is "unpinned by the reference"; the bound/masking applied on top of them is pinned.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+ESTIMATORS = ("dv", "infonce")
+
+
+# ----------------------------------------------------------------------------------------------------
+# a1: pair enumeration (main_utils.py:88-110)
+# ----------------------------------------------------------------------------------------------------
+def sid_to_int(study_id: Sequence) -> np.ndarray:
+    """Map arbitrary hashable study ids (strings in the reference, model_utils.py:212) to int64 codes so
+    that equality is preserved.  The reference only ever compares ids with ``!=`` (main_utils.py:105)."""
+    table: Dict[object, int] = {}
+    out = np.empty(len(study_id), dtype=np.int64)
+    for n, s in enumerate(study_id):
+        if torch.is_tensor(s):
+            s = s.item()
+        out[n] = table.setdefault(s, len(table))
+    return out
+
+
+def pair_index(study_id: Sequence) -> Tuple[np.ndarray, np.ndarray]:
+    """(I, J) index arrays of the rows of the reference's ``mi_input`` in reference order.
+
+    Rows 0..B-1 are the positives (r, r) (main_utils.py:93).  Then for gap in 0..B-2, for i in 0..B-1:
+    j = i+gap+1 if that is < B else i+gap+1-B; the row is emitted iff study_id[i] != study_id[j]
+    (main_utils.py:99-108)."""
+    sid = sid_to_int(study_id)
+    b = len(sid)
+    pos = np.arange(b, dtype=np.int64)
+    if b < 2:
+        return pos, pos.copy()
+    gap = np.arange(b - 1, dtype=np.int64)[:, None]
+    i = np.arange(b, dtype=np.int64)[None, :]
+    j = (i + gap + 1) % b
+    i = np.broadcast_to(i, j.shape)
+    keep = sid[i] != sid[j]
+    return np.concatenate([pos, i[keep]]), np.concatenate([pos, j[keep]])
+
+
+def pair_index_loops(study_id: Sequence) -> Tuple[List[int], List[int]]:
+    """Pure-Python double loop, line by line as main_utils.py:99-108 (small cases only)."""
+    b = len(study_id)
+    ii = list(range(b))
+    jj = list(range(b))
+    for gap in range(b - 1):
+        for i in range(b):
+            j = i + (gap + 1) if i + (gap + 1) < b else i + (gap + 1) - b
+            if study_id[i] != study_id[j]:
+                ii.append(i)
+                jj.append(j)
+    return ii, jj
+
+
+def create_mi_pairs(embedding_img: torch.Tensor, embedding_txt: torch.Tensor, study_id: Sequence) -> torch.Tensor:
+    """[N, d_img + d_txt] critic input in reference row order (main_utils.py:80-110), built with one gather
+    instead of one ``torch.cat`` per row."""
+    i, j = pair_index(study_id)
+    i = torch.from_numpy(i)
+    j = torch.from_numpy(j)
+    return torch.cat((embedding_img[i], embedding_txt[j]), 1)
+
+
+# ----------------------------------------------------------------------------------------------------
+# a2: concat-MLP critic (model.py:18-32)
+# ----------------------------------------------------------------------------------------------------
+def mlp_forward(rows: torch.Tensor, params: Sequence[torch.Tensor]) -> torch.Tensor:
+    """nn.Sequential(Linear, ReLU, Linear, ReLU, Linear) with params = (W1,b1,W2,b2,W3,b3) in PyTorch
+    [out,in] layout.  F.linear is used on purpose (SURVEY.md hazard H3a)."""
+    w1, b1, w2, b2, w3, b3 = params
+    h = F.relu(F.linear(rows, w1, b1))
+    h = F.relu(F.linear(h, w2, b2))
+    return F.linear(h, w3, b3)
+
+
+# ----------------------------------------------------------------------------------------------------
+# a3 / a4: bound reductions (mi_critics.py:3-12, 14-23)
+# ----------------------------------------------------------------------------------------------------
+def dv_bound_loss(discriminator_logits: torch.Tensor, pos_size: int) -> torch.Tensor:
+    """mi_critics.py:3-12.  Result shape [1] for [N,1] logits.  The log-N constant is float32 in the
+    reference (``.float()``, mi_critics.py:10) whatever the logits dtype."""
+    size = discriminator_logits.shape[0]
+    pos_energy = torch.mean(discriminator_logits[:pos_size])
+    lse = torch.logsumexp(discriminator_logits[pos_size:], dim=0)
+    neg_energy = lse - torch.log(torch.tensor(size - pos_size).float())
+    return neg_energy - pos_energy
+
+
+def infonce_bound_loss(discriminator_logits: torch.Tensor, pos_size: int) -> torch.Tensor:
+    """mi_critics.py:14-23.  Result shape [] for [N,1] logits (mean of the 1-element logsumexp)."""
+    pos_energy = torch.mean(discriminator_logits[:pos_size])
+    lse = torch.logsumexp(discriminator_logits[pos_size:], dim=0)
+    neg_energy = torch.mean(lse)
+    return neg_energy - pos_energy
+
+
+def bound_loss(logits: torch.Tensor, pos_size: int, estimator: str) -> torch.Tensor:
+    if estimator == "dv":
+        return dv_bound_loss(logits, pos_size)
+    if estimator == "infonce":
+        return infonce_bound_loss(logits, pos_size)
+    raise ValueError(f"unknown estimator {estimator!r}")
+
+
+def bound_grad_logits(logits: torch.Tensor, pos_size: int) -> torch.Tensor:
+    """Closed form of d loss / d logits: -1/B on positives, softmax over negatives."""
+    flat = logits.reshape(-1)
+    g = torch.empty_like(flat)
+    g[:pos_size] = -1.0 / pos_size
+    g[pos_size:] = torch.softmax(flat[pos_size:], dim=0)
+    return g.reshape(logits.shape)
+
+
+# ----------------------------------------------------------------------------------------------------
+# a5: the literal call site (main_utils.py:220-226)
+# ----------------------------------------------------------------------------------------------------
+def literal_step(x: torch.Tensor, y: torch.Tensor, study_id: Sequence, params: Sequence[torch.Tensor],
+                 estimator: str, pos_size: Optional[int] = None):
+    """pairs -> mi_discriminator -> mi_critic -> backward, exactly as the reference strings them together.
+    Returns dict(scores [N], loss, dx, dy, dparams (6 tensors))."""
+    x = x.detach().clone().requires_grad_(True)
+    y = y.detach().clone().requires_grad_(True)
+    params = [p.detach().clone().requires_grad_(True) for p in params]
+    mi_input = create_mi_pairs(x, y, study_id)
+    mi_output = mlp_forward(mi_input, params)
+    loss = bound_loss(mi_output, len(study_id) if pos_size is None else pos_size, estimator)
+    loss.sum().backward()
+    return {
+        "scores": mi_output.detach().reshape(-1),
+        "loss": loss.detach(),
+        "dx": x.grad,
+        "dy": y.grad,
+        "dparams": [p.grad for p in params],
+    }
+
+
+# ----------------------------------------------------------------------------------------------------
+# B x B matrix forms (what the HIP kernels compute)
+# ----------------------------------------------------------------------------------------------------
+def negative_mask(study_id: Sequence) -> torch.Tensor:
+    """[B,B] bool: True where (i,j) is a negative row of the reference: i != j and sid_i != sid_j."""
+    sid = torch.from_numpy(sid_to_int(study_id))
+    return sid[:, None] != sid[None, :]  # i == j implies equal ids, so the diagonal is False
+
+
+def bound_from_matrix(scores: torch.Tensor, study_id: Sequence, estimator: str) -> torch.Tensor:
+    """The reference loss evaluated on a [B,B] score matrix S[i,j] = critic(x_i, y_j): positives are the
+    diagonal, negatives the masked off-diagonal entries.  Equal to ``bound_loss`` on the reference-ordered
+    rows because logsumexp/mean do not depend on row order."""
+    b = scores.shape[0]
+    neg = negative_mask(study_id)
+    pos_energy = torch.diagonal(scores).mean()
+    lse = torch.logsumexp(scores[neg], dim=0)
+    if estimator == "dv":
+        n_neg = int(neg.sum())
+        return (lse - torch.log(torch.tensor(n_neg).float()) - pos_energy).reshape(1)
+    if estimator == "infonce":
+        return lse - pos_energy
+    raise ValueError(f"unknown estimator {estimator!r}")
+
+
+def matrix_to_reference_rows(scores: torch.Tensor, study_id: Sequence) -> torch.Tensor:
+    i, j = pair_index(study_id)
+    return scores[torch.from_numpy(i), torch.from_numpy(j)]
+
+
+def concat_scores_matrix(x, y, params, round_fn=None) -> torch.Tensor:
+    """Factorised concat-MLP critic: S[i,j] = MLP([x_i ; y_j]) via U_i + V_j.
+
+    ``round_fn`` (optional) is applied at the points where the 16-bit MFMA path rounds: to
+    H1 = relu(U_i + V_j) and to W2.  With round_fn=None this is plain fp32/fp64."""
+    w1, b1, w2, b2, w3, b3 = params
+    dx = x.shape[1]
+    u = F.linear(x, w1[:, :dx])
+    v = F.linear(y, w1[:, dx:], b1)
+    h1 = F.relu(u[:, None, :] + v[None, :, :])  # [B,B,h1]
+    w2e = w2
+    if round_fn is not None:
+        h1 = round_fn(h1)
+        w2e = round_fn(w2)
+    h2 = F.relu(F.linear(h1, w2e, b2))
+    return F.linear(h2, w3, b3).squeeze(-1)
+
+
+def bilinear_scores(x, y, w, round_fn=None) -> torch.Tensor:
+    """Extension (no reference code): S = (x W) y^T.  round_fn mimics 16-bit operand rounding."""
+    if round_fn is None:
+        return (x @ w) @ y.t()
+    t = round_fn(round_fn(x) @ round_fn(w))
+    return t @ round_fn(y).t()
+
+
+def separable_scores(x, y, wg, wh) -> torch.Tensor:
+    """Extension (no reference code): S = (x Wg)(y Wh)^T."""
+    return (x @ wg) @ (y @ wh).t()
+
+
+def round_bf16(t: torch.Tensor) -> torch.Tensor:
+    return t.to(torch.bfloat16).to(t.dtype)
+
+
+def matrix_step(scores_fn, leaves: Sequence[torch.Tensor], study_id: Sequence, estimator: str):
+    """Autograd through a [B,B] score function; returns scores, loss and grads of ``leaves``."""
+    leaves = [t.detach().clone().requires_grad_(True) for t in leaves]
+    s = scores_fn(*leaves)
+    loss = bound_from_matrix(s, study_id, estimator)
+    loss.sum().backward()
+    return {"scores": s.detach(), "loss": loss.detach(), "grads": [t.grad for t in leaves]}
+
+
+def concat_matrix_step(x, y, study_id, params, estimator: str, round_fn=None, row_block: int = 0):
+    """Full fwd+bwd of the factorised concat-MLP critic.  ``row_block`` > 0 processes i-rows in blocks to
+    bound memory (two passes: LSE first, then gradients) -- used by bench.py's cpu_baseline at large B."""
+    if row_block <= 0 or row_block >= x.shape[0]:
+        out = matrix_step(lambda a, b, *p: concat_scores_matrix(a, b, p, round_fn), [x, y, *params],
+                          study_id, estimator)
+        return {"scores": out["scores"], "loss": out["loss"], "dx": out["grads"][0], "dy": out["grads"][1],
+                "dparams": out["grads"][2:]}
+    return _concat_matrix_step_blocked(x, y, study_id, params, estimator, row_block)
+
+
+def _concat_matrix_step_blocked(x, y, study_id, params, estimator, rb):
+    b = x.shape[0]
+    neg = negative_mask(study_id)
+    n_neg = int(neg.sum())
+    with torch.no_grad():
+        blocks = [concat_scores_matrix(x[s:s + rb], y, params) for s in range(0, b, rb)]
+        s_all = torch.cat(blocks, 0)
+        lse = torch.logsumexp(s_all[neg], dim=0)
+        pos = torch.diagonal(s_all).mean()
+    loss = lse - pos
+    if estimator == "dv":
+        loss = (loss - math.log(float(n_neg))).reshape(1)
+    g = torch.where(neg, torch.exp(s_all - lse), torch.zeros_like(s_all))
+    g = g - torch.eye(b, dtype=s_all.dtype) / b
+    xl = x.detach().clone().requires_grad_(True)
+    yl = y.detach().clone().requires_grad_(True)
+    pl = [p.detach().clone().requires_grad_(True) for p in params]
+    for s in range(0, b, rb):
+        sb = concat_scores_matrix(xl[s:s + rb], yl, pl)
+        (sb * g[s:s + rb]).sum().backward()
+    return {"scores": s_all, "loss": loss, "dx": xl.grad, "dy": yl.grad, "dparams": [p.grad for p in pl]}
+
+
+# ----------------------------------------------------------------------------------------------------
+# closed-form backward of the factorised concat-MLP critic -- used to check autograd-free
+# ----------------------------------------------------------------------------------------------------
+def matrix_grad_scores(scores: torch.Tensor, study_id: Sequence) -> torch.Tensor:
+    """G[i,j] = d loss / d S[i,j]: exp(S - LSE_neg) on negatives, -1/B on the diagonal, 0 on dropped pairs."""
+    b = scores.shape[0]
+    neg = negative_mask(study_id)
+    lse = torch.logsumexp(scores[neg], dim=0)
+    g = torch.where(neg, torch.exp(scores - lse), torch.zeros_like(scores))
+    return g - torch.eye(b, dtype=scores.dtype) / b
+
+
+# ----------------------------------------------------------------------------------------------------
+# deterministic, RNG-free synthetic data (bit-reproducible anywhere: integer hash -> exact float division)
+# ----------------------------------------------------------------------------------------------------
+def hash_uniform(shape: Sequence[int], salt: int, dtype=torch.float32) -> torch.Tensor:
+    """Values in [-0.5, 0.5) from a 32-bit integer hash of the flat index; exact in fp32 and fp64."""
+    n = int(np.prod(shape))
+    idx = np.arange(n, dtype=np.uint64)
+    h = (idx * np.uint64(2654435761) + np.uint64(salt) * np.uint64(40503) + np.uint64(12345)) & np.uint64(0xFFFFFFFF)
+    h ^= h >> np.uint64(15)
+    h = (h * np.uint64(2246822519)) & np.uint64(0xFFFFFFFF)
+    h ^= h >> np.uint64(13)
+    h = (h >> np.uint64(8)).astype(np.float64)  # 24 bits -> exact in fp32
+    v = h / float(1 << 24) - 0.5
+    return torch.from_numpy(v.reshape(tuple(shape))).to(dtype)
+
+
+def synthetic_case(b: int, d_img: int, d_txt: int, h1: int = 1024, h2: int = 512, salt: int = 0,
+                   dup: bool = False, dtype=torch.float32):
+    """Closed-form inputs + critic parameters (make_mlp(d_img+d_txt,[h1,h2]) shapes, model.py:18-32)."""
+    x = hash_uniform((b, d_img), salt * 16 + 1, dtype) * 2.0
+    y = hash_uniform((b, d_txt), salt * 16 + 2, dtype) * 2.0
+    d = d_img + d_txt
+    w1 = hash_uniform((h1, d), salt * 16 + 3, dtype) * (2.0 / math.sqrt(d))
+    b1 = hash_uniform((h1,), salt * 16 + 4, dtype) * (2.0 / math.sqrt(d))
+    w2 = hash_uniform((h2, h1), salt * 16 + 5, dtype) * (2.0 / math.sqrt(h1))
+    b2 = hash_uniform((h2,), salt * 16 + 6, dtype) * (2.0 / math.sqrt(h1))
+    w3 = hash_uniform((1, h2), salt * 16 + 7, dtype) * (2.0 / math.sqrt(h2)) * 8.0
+    b3 = hash_uniform((1,), salt * 16 + 8, dtype) * (2.0 / math.sqrt(h2))
+    sid = [str(50000000 + n) for n in range(b)]
+    if dup:  # SURVEY.md 8d "duplicates variant": sid_i = i - (i mod 2) for i < max(B/8, 4)
+        for n in range(max(b // 8, min(b, 4))):
+            sid[n] = str(50000000 + n - (n % 2))
+    return x, y, sid, [w1, b1, w2, b2, w3, b3]
