@@ -1,0 +1,155 @@
+/*
+ * mi_critic.h -- C ABI of the MI355X-native mutual-information critic path (libmi_critic_hip.so).
+ *
+ * The reference (vnoz/Mutual-Information-MultiModal) is pure Python and has no FFI; the interface each entry
+ * point replaces is therefore a Python callable.  Citations are file:line relative to the reference root.
+ *
+ *   mi_bound_*            <- mutual_info_img_txt/mi_critics.py:3-12  (dv_bound_loss)
+ *                            mutual_info_img_txt/mi_critics.py:14-23 (infonce_bound_loss)
+ *   mi_pair_index,
+ *   mi_create_pairs*      <- MultiModalManager.create_mi_pairs, mutual_info_img_txt/main_utils.py:80-110
+ *   mi_concat_mlp_*       <- the call site mutual_info_img_txt/main_utils.py:220-226:
+ *                            create_mi_pairs -> mi_discriminator (make_mlp(1536,[1024,512]), model.py:18-32,
+ *                            instantiated main_utils.py:77) -> mi_critic -> loss.backward()
+ *   mi_bilinear_*         <- same call site with the bilinear critic S = (X W) Y^T named by BASELINE.json
+ *                            (an extension: the reference has no bilinear critic; the bound, the masking and the
+ *                            pair semantics applied to its scores are the reference's)
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the name ends in _host; all tensors are dense row-major
+ *   - embeddings, parameters, scores and gradients are float32 (the reference is fp32 throughout);
+ *     study ids are int64 codes (equal code <=> equal study id; the reference compares ids with != only,
+ *     main_utils.py:105)
+ *   - `stream` is a hipStream_t passed as void*; calls only enqueue work on it and never synchronise
+ *     (the reference synchronises only at loss.item(), main_utils.py:233); the only exception is
+ *     mi_pairs_count_host, which returns a host integer
+ *   - the callee never allocates or frees: outputs, saved statistics and workspace are caller-owned;
+ *     query sizes with the *_workspace_bytes functions
+ *   - return value: 0 on success, negative MI_E* code on failure; mi_last_error() describes the last failure
+ *     on the calling thread.  No C++ exception crosses this boundary.
+ *   - re-entrant, no global state; forward and backward may be called from different host threads
+ *
+ * estimator: MI_DV = 0 (loss = LSE(neg) - log N_neg - mean(pos)), MI_INFONCE = 1 (no log N_neg term).
+ * precision: MI_PREC_F32 = 0 (fp32-input MFMA, exact fp32 products, parity mode),
+ *            MI_PREC_BF16 = 1 (bf16 MFMA operands, fp32 accumulate).
+ */
+#ifndef MI_CRITIC_H
+#define MI_CRITIC_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MI_OK 0
+#define MI_EINVAL (-1)   /* bad argument (null pointer, negative size, unknown enum) */
+#define MI_ESHAPE (-2)   /* shape not supported by the fused kernels */
+#define MI_EWORKSPACE (-3) /* workspace too small */
+#define MI_EHIP (-4)     /* a HIP runtime call failed */
+
+#define MI_DV 0
+#define MI_INFONCE 1
+
+#define MI_PREC_F32 0
+#define MI_PREC_BF16 1
+
+/* Statistics block written by every forward call and read by the matching backward call (64 bytes). */
+typedef struct mi_stats {
+  float lse;          /* log-sum-exp over the negative scores                                  */
+  float pos_mean;     /* mean of the positive scores                                           */
+  float loss_dv;      /* lse - log(n_neg) - pos_mean      (mi_critics.py:10,12)                */
+  float loss_infonce; /* lse - pos_mean                   (mi_critics.py:21,23)                */
+  float log_n_neg;    /* logf((float)n_neg), float32 as in the reference (mi_critics.py:10)    */
+  float neg_max;      /* running maximum of the negative scores                                */
+  float reserved0, reserved1;
+  int64_t n_neg;      /* number of negative rows N - pos_size                                  */
+  int64_t n_pos;      /* pos_size                                                              */
+  int64_t reserved2, reserved3;
+} mi_stats;
+
+int mi_abi_version(void);
+const char* mi_last_error(void);
+
+/* ---- a3 / a4: bound on materialised logits (mi_critics.py:3-23) ------------------------------------ */
+size_t mi_bound_workspace_bytes(int64_t n);
+/* logits[n] (the reference's [N,1] tensor), first pos_size rows positive.  Writes *stats and loss_out[0]. */
+int mi_bound_fwd(const float* logits, int64_t n, int64_t pos_size, int estimator, float* loss_out,
+                 mi_stats* stats, void* workspace, size_t workspace_bytes, void* stream);
+/* grad_logits[r] = grad_out[0] * (r < pos ? -1/pos : exp(logits[r] - lse)); identical for both estimators. */
+int mi_bound_bwd(const float* logits, int64_t n, int64_t pos_size, const mi_stats* stats, const float* grad_out,
+                 float* grad_logits, void* stream);
+
+/* ---- bound on a B x B score matrix with study-id masking ------------------------------------------- */
+/* positives = diagonal; negatives = (i != j and sid[i] != sid[j]); other pairs are dropped (main_utils.py:105) */
+size_t mi_matrix_bound_workspace_bytes(int64_t b);
+int mi_matrix_bound_fwd(const float* scores, const int64_t* sid, int64_t b, int estimator, float* loss_out,
+                        mi_stats* stats, void* workspace, size_t workspace_bytes, void* stream);
+/* grad_scores[i,j] = grad_out[0] * dloss/dS[i,j] */
+int mi_matrix_bound_bwd(const float* scores, const int64_t* sid, int64_t b, const mi_stats* stats,
+                        const float* grad_out, float* grad_scores, void* stream);
+
+/* ---- a1: pair builder (main_utils.py:80-110) ------------------------------------------------------- */
+/* number of rows N of mi_input for these ids (host result; synchronises the stream) */
+int mi_pairs_count_host(const int64_t* sid, int64_t b, int64_t* n_rows_host, void* workspace,
+                        size_t workspace_bytes, void* stream);
+size_t mi_pair_index_workspace_bytes(int64_t b);
+/* pair_i/pair_j[capacity] receive the (i,j) of every row in reference order (positives first, then gap-major /
+ * i-minor negatives); n_rows_dev[0] receives N.  rowpos (optional, [b*(b-1)] int32) receives for every (gap,i)
+ * the output row or -1 when the pair is dropped. */
+int mi_pair_index(const int64_t* sid, int64_t b, int32_t* pair_i, int32_t* pair_j, int64_t capacity,
+                  int64_t* n_rows_dev, int32_t* rowpos, void* workspace, size_t workspace_bytes, void* stream);
+/* out[n_rows, d_img + d_txt] = [img[pair_i[r]] ; txt[pair_j[r]]] */
+int mi_create_pairs(const float* embedding_img, const float* embedding_txt, const int32_t* pair_i,
+                    const int32_t* pair_j, int64_t n_rows, int64_t d_img, int64_t d_txt, float* out, void* stream);
+/* grad_img[i] = sum of grad_out rows whose image index is i (left part), same for txt (right part); fixed
+ * summation order (positive row, then gaps ascending). */
+int mi_create_pairs_bwd(const float* grad_out, const int32_t* rowpos, int64_t b, int64_t d_img, int64_t d_txt,
+                        float* grad_img, float* grad_txt, void* stream);
+
+/* ---- fused bilinear critic: S = (X W) Y^T, bound, all gradients ------------------------------------- */
+/* X [b_rows, d_img] (the local row block), Y [b, d_txt] (all columns), W [d_img, d_txt], sid_rows [b_rows],
+ * sid_cols [b]; row_offset = global index of local row 0 (diagonal of the global B x B matrix).  Single GPU:
+ * b_rows = b, row_offset = 0.  scores_out (optional) [b_rows, b].  w == NULL selects the separable form
+ * S = X Y^T on already-projected embeddings (d_img == d_txt; grad_w unused). */
+size_t mi_bilinear_workspace_bytes(int64_t b_rows, int64_t b, int64_t d_img, int64_t d_txt, int precision);
+int mi_bilinear_fwd(const float* x, const float* y, const float* w, const int64_t* sid_rows,
+                    const int64_t* sid_cols, int64_t b_rows, int64_t b, int64_t row_offset, int64_t d_img,
+                    int64_t d_txt, int estimator, int precision, float* loss_out, mi_stats* stats,
+                    float* partials_out, float* scores_out, void* workspace, size_t workspace_bytes, void* stream);
+/* stats must hold the GLOBAL lse / n_pos (after the cross-rank merge when sharded). grad_out[0] = dL/dloss.
+ * Outputs: grad_x [b_rows, d_img], grad_y [b, d_txt] (partial over this row block), grad_w [d_img, d_txt]. */
+int mi_bilinear_bwd(const float* x, const float* y, const float* w, const int64_t* sid_rows,
+                    const int64_t* sid_cols, int64_t b_rows, int64_t b, int64_t row_offset, int64_t d_img,
+                    int64_t d_txt, int precision, const mi_stats* stats, const float* grad_out, float* grad_x,
+                    float* grad_y, float* grad_w, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- fused concat-MLP critic (the reference's mi_discriminator) ------------------------------------ */
+/* params in PyTorch [out,in] layout: w1 [h1, d_img+d_txt], b1 [h1], w2 [h2, h1], b2 [h2], w3 [h2], b3 [1]. */
+size_t mi_concat_mlp_workspace_bytes(int64_t b_rows, int64_t b, int64_t d_img, int64_t d_txt, int64_t h1,
+                                     int64_t h2, int precision, int need_grad);
+int mi_concat_mlp_fwd(const float* x, const float* y, const float* w1, const float* b1, const float* w2,
+                      const float* b2, const float* w3, const float* b3, const int64_t* sid_rows,
+                      const int64_t* sid_cols, int64_t b_rows, int64_t b, int64_t row_offset, int64_t d_img,
+                      int64_t d_txt, int64_t h1, int64_t h2, int estimator, int precision, int need_grad,
+                      float* loss_out, mi_stats* stats, float* partials_out, float* scores_out /* [b_rows,b] */,
+                      void* workspace, size_t workspace_bytes, void* stream);
+int mi_concat_mlp_bwd(const float* x, const float* y, const float* w1, const float* b1, const float* w2,
+                      const float* b2, const float* w3, const float* b3, const int64_t* sid_rows,
+                      const int64_t* sid_cols, int64_t b_rows, int64_t b, int64_t row_offset, int64_t d_img,
+                      int64_t d_txt, int64_t h1, int64_t h2, int precision, const mi_stats* stats,
+                      const float* grad_out, const float* scores /* [b_rows,b] from fwd */, float* grad_x,
+                      float* grad_y, float* grad_w1, float* grad_b1, float* grad_w2, float* grad_b2,
+                      float* grad_w3, float* grad_b3, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- cross-rank merge of per-rank partial statistics (global-batch negatives) -------- */
+/* partials [n_ranks][4] = (neg_max, sum exp(s - neg_max), sum of positives, n_neg as float pair) gathered in
+ * rank order; writes the global stats and loss.  Merging in rank order makes every rank compute identical bits. */
+int mi_merge_partials(const float* partials, int64_t n_ranks, int64_t n_pos_global, int estimator,
+                      float* loss_out, mi_stats* stats, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI_CRITIC_H */

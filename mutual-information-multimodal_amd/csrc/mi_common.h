@@ -1,0 +1,145 @@
+// Shared device/host helpers for libmi_critic_hip.so (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <math.h>
+
+#include "../../include/mi_critic.h"
+
+namespace mi {
+
+// ------------------------------------------------------------------------------------------------ errors
+void set_error(const char* fmt, ...);
+int hip_fail(hipError_t e, const char* what);
+
+#define MI_CHECK_ARG(cond, ...)        \
+  do {                                 \
+    if (!(cond)) {                     \
+      ::mi::set_error(__VA_ARGS__);    \
+      return MI_EINVAL;                \
+    }                                  \
+  } while (0)
+
+#define MI_LAUNCH_CHECK(what)                                   \
+  do {                                                          \
+    hipError_t e__ = hipGetLastError();                         \
+    if (e__ != hipSuccess) return ::mi::hip_fail(e__, what);    \
+  } while (0)
+
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// Bump allocator over the caller's workspace (never allocates).
+struct Workspace {
+  char* base;
+  size_t size;
+  size_t off;
+  Workspace(void* p, size_t n) : base((char*)p), size(n), off(0) {}
+  template <typename T>
+  T* take(size_t count) {
+    off = align_up(off, 256);
+    T* p = (T*)(base ? base + off : nullptr);
+    off += count * sizeof(T);
+    return p;
+  }
+  bool ok() const { return off <= size && (base != nullptr || off == 0); }
+};
+
+// ------------------------------------------------------------------------------------------------ types
+typedef __bf16 bf16_t;
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+// Partial record of the bound reduction: merged in a fixed order, so results are bit-reproducible.
+struct Partial {
+  float m;    // max of the negative scores seen (or -inf)
+  float s;    // sum exp(score - m)
+  float pos;  // sum of positive scores
+  unsigned cnt;  // number of negatives
+};
+
+#define MI_NEG_INF (-__builtin_inff())
+
+// (m, s) <- (m, s) (+) x
+__device__ __forceinline__ void lse_push(float& m, float& s, float x) {
+  if (x > m) {
+    s = s * expf(m - x) + 1.0f;  // m == -inf: s == 0 and exp(-inf) == 0
+    m = x;
+  } else {
+    s += expf(x - m);
+  }
+}
+// (m, s) <- (m, s) (+) (m2, s2); safe for empty sets (m == -inf, s == 0)
+__device__ __forceinline__ void lse_merge(float& m, float& s, float m2, float s2) {
+  float mm = fmaxf(m, m2);
+  if (mm == MI_NEG_INF) {
+    m = mm;
+    s = 0.0f;
+    return;
+  }
+  s = s * expf(m - mm) + s2 * expf(m2 - mm);
+  m = mm;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ unsigned wave_sum_u(unsigned v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ void wave_lse(float& m, float& s) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    float m2 = __shfl_xor(m, o);
+    float s2 = __shfl_xor(s, o);
+    lse_merge(m, s, m2, s2);
+  }
+}
+
+// Reduce a Partial over a workgroup of NWAVES*64 threads; result valid in thread 0.  `scratch` holds
+// NWAVES Partials.  All threads must call.
+template <int NWAVES>
+__device__ __forceinline__ Partial block_reduce_partial(Partial p, Partial* scratch) {
+  wave_lse(p.m, p.s);
+  p.pos = wave_sum(p.pos);
+  p.cnt = wave_sum_u(p.cnt);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) scratch[wave] = p;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    Partial r = scratch[0];
+    for (int w = 1; w < NWAVES; ++w) {
+      lse_merge(r.m, r.s, scratch[w].m, scratch[w].s);
+      r.pos += scratch[w].pos;
+      r.cnt += scratch[w].cnt;
+    }
+    p = r;
+  }
+  __syncthreads();
+  return p;
+}
+
+// d loss / d score of one pair given the global statistics.
+// kind: 0 dropped, 1 positive (diagonal), 2 negative.
+__device__ __forceinline__ int pair_kind(int64_t gi, int64_t gj, int64_t sid_i, int64_t sid_j) {
+  if (gi == gj) return 1;
+  return sid_i != sid_j ? 2 : 0;
+}
+
+// launchers shared between translation units --------------------------------------------------------
+// partials[n_partials] -> stats, loss_out (one workgroup).  local_record (optional, 8 floats) receives the
+// merged (m, s, pos, cnt_lo, cnt_hi) for the cross-rank merge.
+int launch_finalize(const Partial* partials, int64_t n_partials, int64_t n_pos, int estimator, float* loss_out,
+                    mi_stats* stats, float* local_record, hipStream_t stream);
+
+}  // namespace mi

@@ -1,0 +1,124 @@
+"""ctypes binding of libmi_critic_hip.so (the C ABI declared in include/mi_critic.h).
+
+PyTorch is plumbing here: it owns device memory and the stream; every compute call goes through the C ABI.
+There is no CPU fallback: a missing library or a CPU tensor is an error.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
+from typing import Optional
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_PKG_ROOT = os.path.dirname(_HERE)
+LIB_PATH = os.environ.get("MI_CRITIC_LIB", os.path.join(_PKG_ROOT, "lib", "libmi_critic_hip.so"))
+
+MI_DV, MI_INFONCE = 0, 1
+MI_PREC_F32, MI_PREC_BF16 = 0, 1
+ESTIMATORS = {"dv": MI_DV, "infonce": MI_INFONCE}
+PRECISIONS = {"f32": MI_PREC_F32, "fp32": MI_PREC_F32, "float32": MI_PREC_F32, "bf16": MI_PREC_BF16,
+              "bfloat16": MI_PREC_BF16}
+STATS_BYTES = 64
+RECORD_FLOATS = 8
+
+# name -> (restype, argtypes); must list every symbol of include/mi_critic.h (tests/test_abi.py checks this)
+_P, _I64, _I, _SZ = c_void_p, c_int64, c_int, c_size_t
+SIGNATURES = {
+    "mi_abi_version": (c_int, []),
+    "mi_last_error": (c_char_p, []),
+    "mi_bound_workspace_bytes": (_SZ, [_I64]),
+    "mi_bound_fwd": (c_int, [_P, _I64, _I64, _I, _P, _P, _P, _SZ, _P]),
+    "mi_bound_bwd": (c_int, [_P, _I64, _I64, _P, _P, _P, _P]),
+    "mi_matrix_bound_workspace_bytes": (_SZ, [_I64]),
+    "mi_matrix_bound_fwd": (c_int, [_P, _P, _I64, _I, _P, _P, _P, _SZ, _P]),
+    "mi_matrix_bound_bwd": (c_int, [_P, _P, _I64, _P, _P, _P, _P]),
+    "mi_pairs_count_host": (c_int, [_P, _I64, ctypes.POINTER(c_int64), _P, _SZ, _P]),
+    "mi_pair_index_workspace_bytes": (_SZ, [_I64]),
+    "mi_pair_index": (c_int, [_P, _I64, _P, _P, _I64, _P, _P, _P, _SZ, _P]),
+    "mi_create_pairs": (c_int, [_P, _P, _P, _P, _I64, _I64, _I64, _P, _P]),
+    "mi_create_pairs_bwd": (c_int, [_P, _P, _I64, _I64, _I64, _P, _P, _P]),
+    "mi_bilinear_workspace_bytes": (_SZ, [_I64, _I64, _I64, _I64, _I]),
+    "mi_bilinear_fwd": (c_int, [_P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I, _I, _P, _P, _P, _P, _P, _SZ, _P]),
+    "mi_bilinear_bwd": (c_int, [_P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I, _P, _P, _P, _P, _P, _P, _SZ, _P]),
+    "mi_concat_mlp_workspace_bytes": (_SZ, [_I64, _I64, _I64, _I64, _I64, _I64, _I, _I]),
+    "mi_concat_mlp_fwd": (c_int, [_P] * 10 + [_I64] * 7 + [_I, _I, _I] + [_P] * 5 + [_SZ, _P]),
+    "mi_concat_mlp_bwd": (c_int, [_P] * 10 + [_I64] * 7 + [_I] + [_P] * 12 + [_SZ, _P]),
+    "mi_merge_partials": (c_int, [_P, _I64, _I64, _I, _P, _P, _P]),
+}
+
+_lib: Optional[ctypes.CDLL] = None
+
+
+class MiCriticError(RuntimeError):
+    pass
+
+
+def load() -> ctypes.CDLL:
+    """Load the HIP library, failing loudly when it is missing (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.isfile(LIB_PATH):
+        raise MiCriticError(
+            f"HIP library not found at {LIB_PATH}. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            f"or `make -C {os.path.join(_PKG_ROOT, 'csrc')}`. There is no CPU fallback for the MI critic path.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc == 0:
+        return
+    msg = load().mi_last_error()
+    msg = msg.decode() if msg else ""
+    if rc in (-1, -2):
+        raise ValueError(f"{what}: {msg} (code {rc})")
+    raise MiCriticError(f"{what}: {msg} (code {rc})")
+
+
+def stream_ptr() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def require_device(t: torch.Tensor, name: str) -> None:
+    if not torch.is_tensor(t):
+        raise TypeError(f"{name} must be a torch.Tensor")
+    if not t.is_cuda:
+        raise MiCriticError(f"{name} is on {t.device}: the MI critic path runs only on a ROCm device "
+                            "(no CPU fallback; the CPU oracle under oracle/ is test infrastructure)")
+
+
+def f32c(t: torch.Tensor, name: str) -> torch.Tensor:
+    require_device(t, name)
+    if t.dtype != torch.float32:
+        raise TypeError(f"{name} must be float32 (got {t.dtype}); the reference path is fp32 throughout")
+    return t.contiguous()
+
+
+def workspace(nbytes: int, device) -> torch.Tensor:
+    return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+
+
+def new_stats(device) -> torch.Tensor:
+    return torch.empty(STATS_BYTES, dtype=torch.uint8, device=device)
+
+
+def stats_dict(stats: torch.Tensor) -> dict:
+    """Host copy of a statistics block (synchronises)."""
+    raw = stats.cpu()
+    f = raw[:32].view(torch.float32)
+    i = raw[32:].view(torch.int64)
+    return {"lse": float(f[0]), "pos_mean": float(f[1]), "loss_dv": float(f[2]), "loss_infonce": float(f[3]),
+            "log_n_neg": float(f[4]), "neg_max": float(f[5]), "n_neg": int(i[0]), "n_pos": int(i[1])}
