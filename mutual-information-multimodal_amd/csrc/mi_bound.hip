@@ -152,7 +152,7 @@ __global__ __launch_bounds__(kBlock) void bound_bwd_kernel(const float* __restri
 
 // scores [b_rows, b]; row r is global row row_offset + r.  One workgroup walks whole rows (no integer division),
 // 16-byte loads when the row pitch allows.
-__global__ __launch_bounds__(kBlock) void matrix_partials_kernel(const float* __restrict__ scores,
+__global__ __launch_bounds__(256) void matrix_partials_kernel(const float* __restrict__ scores,
                                                                  const int64_t* __restrict__ sid_rows,
                                                                  const int64_t* __restrict__ sid_cols,
                                                                  int64_t b_rows, int64_t b, int64_t row_offset,

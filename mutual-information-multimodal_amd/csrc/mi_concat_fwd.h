@@ -1,0 +1,295 @@
+// Fused concat-MLP critic, forward:  S[i,j] = w3 . relu(W2 relu(U_i + V_j) + b2) + b3
+//   reference: create_mi_pairs (main_utils.py:80-110) -> make_mlp(1536,[1024,512]) (model.py:18-32, main_utils.py:77)
+//   with the first Linear factorised: W1 [x_i ; y_j] + b1 = U_i + V_j, U = X W1x^T, V = Y W1y^T + b1.
+//
+// One 512-thread workgroup (8 waves, 2 per SIMD) owns a pair tile of 8 image rows x 32 text columns = 256 pairs and
+// runs H2/256 passes; in a pass it accumulates Z2^T[n, pair] for 256 hidden units n over all H1 = K:
+//     A operand (MFMA rows  = n)    : W2[n, k]  streamed HBM/L2 -> registers -> LDS (double-buffered k tiles)
+//     B operand (MFMA cols  = pair) : H1[pair, k] = relu(U_i[k] + V_j[k]) generated in registers from small U/V tiles
+// so the [B^2, H1] activation matrix of the reference (34 GB in bf16 at B = 4096) never exists.  The epilogue applies
+// relu and the dot with w3 in registers (b2 is the accumulator's initial value), and, when gradients are needed,
+// emits the sign pattern of Z2 as two bit images used by the backward kernels (1 bit per (pair, n), twice):
+//     bitsP: per pair, 64-bit words indexed [h][pass*2 + wn]; bit q = 16*a + r  <->  n = 256*pass + 128*wn + 32*a +
+//            (r & 3) + 8*(r >> 2) + 4*h        (lane-local MFMA accumulator order; consumed by mi_concat_bwd dU/dV)
+//     bitsN: per (row i, 32-column block), one 32-bit word per n; bit q <-> column 32*block + q   (consumed by dW2)
+// Wave (wn, wp): hidden units [128 wn, +128) of the pass, pairs of local rows {2 wp, 2 wp + 1} x 32 columns:
+// 4 x 2 MFMA 32x32 tiles, 128 accumulator registers.
+#pragma once
+#include <utility>
+
+#include "mi_common.h"
+
+namespace mi {
+
+template <typename OpT>
+struct FwdCfg;
+template <>
+struct FwdCfg<bf16_t> {
+  static constexpr int KT = 64;     // k per staged tile
+  static constexpr int KSTEP = 16;  // k per MFMA
+  static constexpr int LDW = 72;    // W2 tile row pitch in elements (144 B: ds_read_b128 conflict-free)
+  static constexpr int LDUV = 68;   // U/V tile row pitch in floats (272 B)
+};
+template <>
+struct FwdCfg<float> {
+  static constexpr int KT = 32;
+  static constexpr int KSTEP = 2;
+  static constexpr int LDW = 33;
+  static constexpr int LDUV = 33;
+};
+
+#define LANE_OF_REG(r) (((r) & 3) + 8 * ((r) >> 2))
+
+// compile-time unrolled loop: f(std::integral_constant<int, 0>) ... f(std::integral_constant<int, N-1>)
+template <class F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+constexpr int kFwdTI = 8;    // image rows per pair tile
+constexpr int kFwdTJ = 32;   // text columns per pair tile
+constexpr int kFwdNP = 256;  // hidden units per pass
+
+template <typename OpT>
+struct FwdSmem {
+  using Cfg = FwdCfg<OpT>;
+  OpT w[2][kFwdNP * Cfg::LDW];
+  float v[2][kFwdTJ * Cfg::LDUV];
+  float u[2][kFwdTI * Cfg::LDUV];
+  float b2[kFwdNP];
+  float w3[kFwdNP];
+  float sred[2][2][kFwdTI * kFwdTJ];  // [pass parity is folded: accumulated][wn][pair]
+};
+
+// relu(u + v) for 8 consecutive k, packed to bf16 (RNE).  relu on the packed pair as a signed 16-bit max with 0:
+// negative bf16 values have the sign bit set, i.e. are negative int16.
+__device__ __forceinline__ bf16x8 gen_h1_bf16(const f32x4& u0, const f32x4& u1, const f32x4& v0, const f32x4& v1) {
+  union {
+    bf16x8 v;
+    s16x2 s[4];
+  } o;
+  const f32x4 a = u0 + v0, b = u1 + v1;
+  const s16x2 zero = {0, 0};
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    f32x2 p = {a[2 * q], a[2 * q + 1]};
+    o.s[q] = __builtin_elementwise_max(__builtin_bit_cast(s16x2, __builtin_convertvector(p, bf16x2)), zero);
+    f32x2 p2 = {b[2 * q], b[2 * q + 1]};
+    o.s[2 + q] = __builtin_elementwise_max(__builtin_bit_cast(s16x2, __builtin_convertvector(p2, bf16x2)), zero);
+  }
+  return o.v;
+}
+
+// Lanes `lane_lo` and `lane_lo + 4` of `word` receive the low / high half of a wave-uniform 64-bit ballot.
+// v_writelane_b32 has no builtin in this toolchain; the leading s_nop covers the VALU-writes-SGPR -> lane-op hazard
+// (hipcc pads nothing inside an asm statement).
+template <int LANE_LO>
+__device__ __forceinline__ unsigned ballot_to_lanes(unsigned word, unsigned long long bal) {
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)bal);
+  const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(bal >> 32));
+  asm volatile("s_nop 4\n\tv_writelane_b32 %0, %1, %3\n\tv_writelane_b32 %0, %2, %4"
+               : "+v"(word)
+               : "s"(lo), "s"(hi), "n"(LANE_LO), "n"(LANE_LO + 4));
+  return word;
+}
+
+template <typename OpT>
+__global__ __launch_bounds__(512) void concat_fwd_kernel(const float* __restrict__ U, const float* __restrict__ V,
+                                                         const OpT* __restrict__ W2, const float* __restrict__ b2,
+                                                         const float* __restrict__ w3, const float* __restrict__ b3,
+                                                         int64_t b_rows, int64_t b, int H1, int H2,
+                                                         float* __restrict__ S, unsigned long long* __restrict__ bitsP,
+                                                         unsigned* __restrict__ bitsN) {
+  using Cfg = FwdCfg<OpT>;
+  constexpr int KT = Cfg::KT, KSTEP = Cfg::KSTEP, LDW = Cfg::LDW, LDUV = Cfg::LDUV;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  FwdSmem<OpT>& sm = *reinterpret_cast<FwdSmem<OpT>*>(smem_raw);
+
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63;
+  const int wn = wave >> 2, wp = wave & 3;
+  const int c = lane & 31, h = lane >> 5;
+  const int64_t i0 = (int64_t)blockIdx.y * kFwdTI, j0 = (int64_t)blockIdx.x * kFwdTJ;
+  const int n_pass = H2 / kFwdNP;
+  const int n_kt = H1 / KT;
+  const int64_t JB = (b + 31) / 32;
+
+  // ---- staging assignment (global -> registers -> LDS) ---------------------------------------------------------
+  // W2 tile: 256 rows x 128 bytes = 2048 16-byte vectors, 4 per thread.  V tile: 32 rows, U tile: 8 rows.
+  constexpr int VEC_PER_ROW_UV = KT / 4;  // float4 per U/V row
+  const bool has_v = tid < kFwdTJ * VEC_PER_ROW_UV;
+  const bool has_u = tid < kFwdTI * VEC_PER_ROW_UV;
+  const int uv_row = tid / VEC_PER_ROW_UV, uv_kv = tid % VEC_PER_ROW_UV;
+  int64_t vrow_g = j0 + uv_row;
+  if (vrow_g >= b) vrow_g = b - 1;  // clamp: the pair is discarded in the epilogue
+  int64_t urow_g = i0 + uv_row;
+  if (urow_g >= b_rows) urow_g = b_rows - 1;
+  const float* vsrc = V + vrow_g * H1 + uv_kv * 4;
+  const float* usrc = U + urow_g * H1 + uv_kv * 4;
+
+  u32x4 rw[4];
+  f32x4 rv, ru;
+
+  auto stage_load = [&](int pass, int kt) {
+    const int64_t k0 = (int64_t)kt * KT;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int vidx = tid + 512 * q;
+      const int row = vidx >> 3, kv = vidx & 7;
+      const char* src = reinterpret_cast<const char*>(W2 + ((int64_t)(pass * kFwdNP + row)) * H1 + k0) + kv * 16;
+      rw[q] = *reinterpret_cast<const u32x4*>(src);
+    }
+    if (has_v) rv = *reinterpret_cast<const f32x4*>(vsrc + k0);
+    if (has_u) ru = *reinterpret_cast<const f32x4*>(usrc + k0);
+  };
+  auto stage_store = [&](int buf) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int vidx = tid + 512 * q;
+      const int row = vidx >> 3, kv = vidx & 7;
+      if constexpr (sizeof(OpT) == 2) {
+        *reinterpret_cast<u32x4*>(&sm.w[buf][row * LDW + kv * 8]) = rw[q];
+      } else {
+        float* dst = reinterpret_cast<float*>(&sm.w[buf][row * LDW + kv * 4]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const unsigned bits = rw[q][e];  // copy first: bit_cast of a vector-element lvalue miscompiles (ROCm 7.2)
+          dst[e] = __builtin_bit_cast(float, bits);
+        }
+      }
+    }
+    if constexpr (sizeof(OpT) == 2) {
+      if (has_v) *reinterpret_cast<f32x4*>(&sm.v[buf][uv_row * LDUV + uv_kv * 4]) = rv;
+      if (has_u) *reinterpret_cast<f32x4*>(&sm.u[buf][uv_row * LDUV + uv_kv * 4]) = ru;
+    } else {
+      if (has_v) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) sm.v[buf][uv_row * LDUV + uv_kv * 4 + e] = rv[e];
+      }
+      if (has_u) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) sm.u[buf][uv_row * LDUV + uv_kv * 4 + e] = ru[e];
+      }
+    }
+  };
+
+  float s_total[2] = {0.0f, 0.0f};  // per pair-tile t: this lane's partial score (summed over passes)
+
+  for (int pass = 0; pass < n_pass; ++pass) {
+    __syncthreads();  // every wave has left the previous pass's epilogue (it reads sm.w3)
+    // b2 / w3 of this pass's 256 hidden units
+    if (tid < kFwdNP) {
+      sm.b2[tid] = b2[pass * kFwdNP + tid];
+      sm.w3[tid] = w3[pass * kFwdNP + tid];
+    }
+    stage_load(pass, 0);
+    __syncthreads();  // b2/w3 visible; previous pass's LDS reads finished
+    stage_store(0);
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float bias = sm.b2[wn * 128 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * h];
+        acc[a][0][r] = bias;
+        acc[a][1][r] = bias;
+      }
+    __syncthreads();
+
+    for (int kt = 0; kt < n_kt; ++kt) {
+      const int buf = kt & 1;
+      const bool more = kt + 1 < n_kt;
+      if (more) stage_load(pass, kt + 1);
+      const OpT* wt = sm.w[buf];
+      const float* vt = sm.v[buf];
+      const float* ut = sm.u[buf];
+#pragma unroll
+      for (int kk = 0; kk < KT / KSTEP; ++kk) {
+        if constexpr (sizeof(OpT) == 2) {
+          const int ko = kk * 16 + 8 * h;
+          const f32x4 v0 = *reinterpret_cast<const f32x4*>(&vt[c * LDUV + ko]);
+          const f32x4 v1 = *reinterpret_cast<const f32x4*>(&vt[c * LDUV + ko + 4]);
+          bf16x8 hf[2];
+#pragma unroll
+          for (int t = 0; t < 2; ++t) {
+            const f32x4 u0 = *reinterpret_cast<const f32x4*>(&ut[(2 * wp + t) * LDUV + ko]);
+            const f32x4 u1 = *reinterpret_cast<const f32x4*>(&ut[(2 * wp + t) * LDUV + ko + 4]);
+            hf[t] = gen_h1_bf16(u0, u1, v0, v1);
+          }
+#pragma unroll
+          for (int a = 0; a < 4; ++a) {
+            const bf16x8 wf = *reinterpret_cast<const bf16x8*>(&wt[(wn * 128 + a * 32 + c) * LDW + ko]);
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+              acc[a][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, hf[t], acc[a][t], 0, 0, 0);
+          }
+        } else {
+          const int ko = kk * 2 + h;
+          const float vv = vt[c * LDUV + ko];
+          float hv[2];
+#pragma unroll
+          for (int t = 0; t < 2; ++t) hv[t] = fmaxf(ut[(2 * wp + t) * LDUV + ko] + vv, 0.0f);
+#pragma unroll
+          for (int a = 0; a < 4; ++a) {
+            const float wf = wt[(wn * 128 + a * 32 + c) * LDW + ko];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) acc[a][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf, hv[t], acc[a][t], 0, 0, 0);
+          }
+        }
+      }
+      if (more) stage_store(buf ^ 1);
+      __syncthreads();
+    }
+
+    // ---- epilogue of the pass: relu, dot with w3, sign bits ------------------------------------------------------
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int64_t li = i0 + 2 * wp + t;   // local image row of this pair tile
+      const int64_t gj = j0 + c;            // text column of this lane
+      float s = 0.0f;
+      unsigned long long pbits = 0ull;
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        unsigned nword = 0u;  // lanes 0..31 collect the 32-column sign words of hidden units 32a + lane
+        static_for<16>([&](auto rc) {
+          constexpr int r = decltype(rc)::value;
+          const int nl = wn * 128 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+          const float z = acc[a][t][r];
+          const bool pos = z > 0.0f;
+          s += pos ? z * sm.w3[nl] : 0.0f;
+          if (bitsP) {
+            pbits |= (unsigned long long)(pos ? 1u : 0u) << (16 * a + r);
+            const unsigned long long bal = __ballot(pos);
+            nword = ballot_to_lanes<LANE_OF_REG(r)>(nword, bal);
+          }
+        });
+        if (bitsP && lane < 32 && li < b_rows)
+          bitsN[(li * JB + blockIdx.x) * H2 + pass * kFwdNP + wn * 128 + a * 32 + lane] = nword;
+      }
+      if (bitsP && li < b_rows && gj < b) {
+        const int64_t wpp = H2 / 64;  // 64-bit words per pair
+        bitsP[(li * b + gj) * wpp + h * (wpp / 2) + pass * 2 + wn] = pbits;
+      }
+      s_total[t] += s;
+    }
+  }
+
+  // ---- combine: halves (h), hidden-unit waves (wn) -> score -----------------------------------------------------
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    float s = s_total[t] + __shfl_xor(s_total[t], 32);
+    if (h == 0) sm.sred[0][wn][(2 * wp + t) * 32 + c] = s;
+  }
+  __syncthreads();
+  if (tid < kFwdTI * kFwdTJ) {
+    const int il = tid >> 5, jl = tid & 31;
+    const int64_t li = i0 + il, gj = j0 + jl;
+    if (li < b_rows && gj < b) S[li * b + gj] = (sm.sred[0][0][tid] + sm.sred[0][1][tid]) + b3[0];
+  }
+}
+
+}  // namespace mi

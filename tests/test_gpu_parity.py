@@ -264,3 +264,76 @@ def test_bilinear_full_size_properties(dev):
     c = float((yl.grad * y).sum())
     assert abs(a - c) < 2e-2 * max(abs(a), 1e-3) + 1e-4
     assert torch.isfinite(xl.grad).all() and torch.isfinite(critic.weight.grad).all()
+
+
+# ------------------------------------------------------------------------------------------------ fused concat-MLP
+def _mlp_on(dev, d_in, hidden, params):
+    from mutual_info_img_txt.model import make_mlp
+    mlp = make_mlp(d_in, list(hidden))
+    with torch.no_grad():
+        for p, v in zip(mlp.parameters(), params):
+            p.copy_(v)
+    return mlp.to(dev)
+
+
+CONCAT_CASES = [(40, 24, 40, 64, 256, True), (96, 128, 128, 1024, 512, False), (33, 16, 8, 128, 256, True),
+                (130, 32, 32, 64, 512, True)]
+
+
+# fp32 MFMA mode (exact fp32 products): scores |d| <= 2e-5*max(1,|S|max); loss 3e-5
+@pytest.mark.parametrize("b,dx,dy,h1,h2,dup", CONCAT_CASES)
+def test_concat_f32_forward_vs_oracle(dev, b, dx, dy, h1, h2, dup):
+    from mutual_info_img_txt import mi_critics
+    x, y, sid, params = orc.synthetic_case(b, dx, dy, h1=h1, h2=h2, salt=b, dup=dup)
+    mlp = _mlp_on(dev, dx + dy, (h1, h2), params)
+    for est in ("dv", "infonce"):
+        with torch.no_grad():
+            loss, scores = mi_critics.fused_mi_bound(x.to(dev), y.to(dev), sid, mlp, est, precision="f32",
+                                                     return_scores=True)
+        s_ref = orc.concat_scores_matrix(x.double(), y.double(), [p.double() for p in params])
+        l_ref = orc.bound_from_matrix(s_ref, sid, est)
+        sc = max(float(s_ref.abs().max()), 1.0)
+        np.testing.assert_allclose(scores.cpu().numpy(), s_ref.numpy(), rtol=0, atol=2e-5 * sc)
+        np.testing.assert_allclose(loss.cpu().numpy(), l_ref.numpy(), rtol=1e-5, atol=3e-5)
+        assert tuple(loss.shape) == ((1,) if est == "dv" else ())
+
+
+@pytest.mark.parametrize("tag", ["b8_d768", "b32_d768", "b16_d128", "b32_d128", "b16_d768_dup", "b32_d128_dup",
+                                 "b24_d96x160_dup"])
+def test_concat_f32_forward_golden(dev, golden, tag):
+    """Scores in reference row order and both losses against the outputs of the reference's own functions."""
+    from mutual_info_img_txt import mi_critics
+    from mutual_info_img_txt.main_utils import pair_index
+    g = golden("g3_full_step.npz")
+    b, di, dt_, dup, salt = [int(v) for v in g[f"{tag}/meta"]]
+    x, y, sid, params = orc.synthetic_case(b, di, dt_, salt=salt, dup=bool(dup))
+    mlp = _mlp_on(dev, di + dt_, (1024, 512), params)
+    pi, pj = pair_index(sid, dev)
+    for est in ("dv", "infonce"):
+        with torch.no_grad():
+            loss, scores = mi_critics.fused_mi_bound(x.to(dev), y.to(dev), sid, mlp, est, precision="f32",
+                                                     return_scores=True)
+        rows = scores[pi.long(), pj.long()].cpu().numpy()
+        ref = g[f"{tag}/f64/scores"]
+        assert rows.shape == ref.shape == (int(g[f"{tag}/{est}/f64/n_rows"]),)
+        np.testing.assert_allclose(rows, ref, rtol=0, atol=2e-5 * max(1.0, np.abs(ref).max()))
+        np.testing.assert_allclose(loss.cpu().numpy(), g[f"{tag}/{est}/f64/loss"], rtol=1e-5, atol=3e-5)
+
+
+# bf16 MFMA mode against an oracle that rounds H1 and W2 to bf16 (the kernel's rounding points): 3e-3*scale;
+# against the unrounded oracle the documented tolerance is 3e-2*scale.
+@pytest.mark.parametrize("b,dx,dy,h1,h2,dup", CONCAT_CASES[:2])
+def test_concat_bf16_forward_vs_rounded_oracle(dev, b, dx, dy, h1, h2, dup):
+    from mutual_info_img_txt import mi_critics
+    x, y, sid, params = orc.synthetic_case(b, dx, dy, h1=h1, h2=h2, salt=b, dup=dup)
+    mlp = _mlp_on(dev, dx + dy, (h1, h2), params)
+    with torch.no_grad():
+        loss, scores = mi_critics.fused_mi_bound(x.to(dev), y.to(dev), sid, mlp, "dv", precision="bf16",
+                                                 return_scores=True)
+    p64 = [p.double() for p in params]
+    s_r = orc.concat_scores_matrix(x.double(), y.double(), p64, round_fn=orc.round_bf16)
+    s_f = orc.concat_scores_matrix(x.double(), y.double(), p64)
+    sc = max(float(s_f.abs().max()), 1.0)
+    np.testing.assert_allclose(scores.cpu().numpy(), s_r.numpy(), rtol=0, atol=3e-3 * sc)
+    np.testing.assert_allclose(scores.cpu().numpy(), s_f.numpy(), rtol=0, atol=3e-2 * sc)
+    assert abs(float(loss) - float(orc.bound_from_matrix(s_r, sid, "dv"))) < 3e-3 * sc
