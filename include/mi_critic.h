@@ -72,6 +72,12 @@ typedef struct mi_stats {
 int mi_abi_version(void);
 const char* mi_last_error(void);
 
+/* Optional per-kernel timing (bench.py's roofline leg): between mi_profile_begin and mi_profile_end every kernel
+ * launch of this library is bracketed by HIP events on its stream.  mi_profile_end synchronises the device and returns
+ * up to `capacity` (name, milliseconds) records in launch order; names is a NUL-separated list.  Not thread-safe. */
+int mi_profile_begin(void);
+int mi_profile_end(char* names, size_t names_bytes, float* ms, int capacity, int* n_out);
+
 /* ---- a3 / a4: bound on materialised logits (mi_critics.py:3-23) ------------------------------------ */
 size_t mi_bound_workspace_bytes(int64_t n);
 /* logits[n] (the reference's [N,1] tensor), first pos_size rows positive.  Writes *stats and loss_out[0]. */

@@ -5,6 +5,8 @@
 #include <stdarg.h>
 #include <string.h>
 
+#include <vector>
+
 #include "mi_common.h"
 
 namespace mi {
@@ -20,6 +22,35 @@ void set_error(const char* fmt, ...) {
 int hip_fail(hipError_t e, const char* what) {
   set_error("%s: %s", what, hipGetErrorString(e));
   return MI_EHIP;
+}
+
+// ------------------------------------------------------------------------------------------------ profiling
+struct ProfEntry {
+  const char* name;
+  hipEvent_t a, b;
+};
+static bool g_prof_on = false;
+static std::vector<ProfEntry> g_prof;
+static std::vector<hipEvent_t> g_prof_pool;
+bool profile_enabled() { return g_prof_on; }
+static hipEvent_t prof_event() {
+  if (!g_prof_pool.empty()) {
+    hipEvent_t e = g_prof_pool.back();
+    g_prof_pool.pop_back();
+    return e;
+  }
+  hipEvent_t e;
+  hipEventCreate(&e);
+  return e;
+}
+void profile_push(const char* name, hipStream_t st, bool begin) {
+  if (begin) {
+    ProfEntry e{name, prof_event(), prof_event()};
+    hipEventRecord(e.a, st);
+    g_prof.push_back(e);
+  } else {
+    hipEventRecord(g_prof.back().b, st);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------ kernels
@@ -233,8 +264,11 @@ static int grid_for(int64_t n_items) {
 
 int launch_finalize(const Partial* partials, int64_t n_partials, int64_t n_pos, int estimator, float* loss_out,
                     mi_stats* stats, float* local_record, hipStream_t stream) {
-  hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(kBlock), 0, stream, partials, n_partials, n_pos, estimator,
-                     loss_out, stats, local_record);
+  {
+    ProfScope prof_("finalize_kernel", stream);
+    hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(kBlock), 0, stream, partials, n_partials, n_pos, estimator,
+                       loss_out, stats, local_record);
+  }
   MI_LAUNCH_CHECK("finalize_kernel");
   return MI_OK;
 }
@@ -246,6 +280,38 @@ using namespace mi;
 extern "C" {
 
 int mi_abi_version(void) { return 1; }
+
+int mi_profile_begin(void) {
+  for (auto& e : mi::g_prof) {
+    mi::g_prof_pool.push_back(e.a);
+    mi::g_prof_pool.push_back(e.b);
+  }
+  mi::g_prof.clear();
+  mi::g_prof_on = true;
+  return MI_OK;
+}
+
+int mi_profile_end(char* names, size_t names_bytes, float* ms, int capacity, int* n_out) {
+  mi::g_prof_on = false;
+  MI_CHECK_ARG(names && ms && n_out, "mi_profile_end: null pointer");
+  hipError_t err = hipDeviceSynchronize();
+  if (err != hipSuccess) return hip_fail(err, "hipDeviceSynchronize");
+  int n = 0;
+  size_t off = 0;
+  for (auto& e : mi::g_prof) {
+    if (n >= capacity) break;
+    const size_t len = strlen(e.name) + 1;
+    if (off + len > names_bytes) break;
+    float t = 0.0f;
+    hipEventElapsedTime(&t, e.a, e.b);
+    ms[n] = t;
+    memcpy(names + off, e.name, len);  // NUL-separated list
+    off += len;
+    ++n;
+  }
+  *n_out = n;
+  return MI_OK;
+}
 const char* mi_last_error(void) { return mi::g_err; }
 
 size_t mi_bound_workspace_bytes(int64_t n) {
@@ -267,7 +333,10 @@ int mi_bound_fwd(const float* logits, int64_t n, int64_t pos_size, int estimator
   }
   const int grid = grid_for(n);
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(bound_partials_kernel, dim3(grid), dim3(kBlock), 0, st, logits, n, pos_size, partials);
+  {
+    ProfScope prof_("bound_partials_kernel", st);
+    hipLaunchKernelGGL(bound_partials_kernel, dim3(grid), dim3(kBlock), 0, st, logits, n, pos_size, partials);
+  }
   MI_LAUNCH_CHECK("bound_partials_kernel");
   return launch_finalize(partials, grid, pos_size, estimator, loss_out, stats, nullptr, st);
 }
@@ -277,8 +346,11 @@ int mi_bound_bwd(const float* logits, int64_t n, int64_t pos_size, const mi_stat
   MI_CHECK_ARG(logits && stats && grad_logits, "mi_bound_bwd: null pointer");
   MI_CHECK_ARG(n >= 0 && pos_size >= 0 && pos_size <= n, "mi_bound_bwd: bad sizes");
   if (n == 0) return MI_OK;
-  hipLaunchKernelGGL(bound_bwd_kernel, dim3(grid_for(n)), dim3(kBlock), 0, (hipStream_t)stream, logits, n, pos_size,
-                     stats, grad_out, grad_logits);
+  {
+    ProfScope prof_("bound_bwd_kernel", (hipStream_t)stream);
+    hipLaunchKernelGGL(bound_bwd_kernel, dim3(grid_for(n)), dim3(kBlock), 0, (hipStream_t)stream, logits, n, pos_size,
+                       stats, grad_out, grad_logits);
+  }
   MI_LAUNCH_CHECK("bound_bwd_kernel");
   return MI_OK;
 }
@@ -298,8 +370,11 @@ int mi_matrix_bound_fwd(const float* scores, const int64_t* sid, int64_t b, int 
   }
   const int grid = grid_rows(b);
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(matrix_partials_kernel, dim3(grid), dim3(kBlock), 0, st, scores, sid, sid, b, b, (int64_t)0,
-                     partials);
+  {
+    ProfScope prof_("matrix_partials_kernel", st);
+    hipLaunchKernelGGL(matrix_partials_kernel, dim3(grid), dim3(kBlock), 0, st, scores, sid, sid, b, b, (int64_t)0,
+                       partials);
+  }
   MI_LAUNCH_CHECK("matrix_partials_kernel");
   return launch_finalize(partials, grid, b, estimator, loss_out, stats, nullptr, st);
 }
@@ -308,8 +383,11 @@ int mi_matrix_bound_bwd(const float* scores, const int64_t* sid, int64_t b, cons
                         const float* grad_out, float* grad_scores, void* stream) {
   MI_CHECK_ARG(scores && sid && stats && grad_scores, "mi_matrix_bound_bwd: null pointer");
   MI_CHECK_ARG(b >= 1, "mi_matrix_bound_bwd: b must be >= 1");
-  hipLaunchKernelGGL(matrix_bwd_kernel, dim3(grid_rows(b)), dim3(kBlock), 0, (hipStream_t)stream, scores, sid, sid,
-                     b, b, (int64_t)0, stats, grad_out, grad_scores);
+  {
+    ProfScope prof_("matrix_bwd_kernel", (hipStream_t)stream);
+    hipLaunchKernelGGL(matrix_bwd_kernel, dim3(grid_rows(b)), dim3(kBlock), 0, (hipStream_t)stream, scores, sid, sid,
+                       b, b, (int64_t)0, stats, grad_out, grad_scores);
+  }
   MI_LAUNCH_CHECK("matrix_bwd_kernel");
   return MI_OK;
 }
@@ -319,8 +397,11 @@ int mi_merge_partials(const float* partials, int64_t n_ranks, int64_t n_pos_glob
   MI_CHECK_ARG(partials && stats, "mi_merge_partials: null pointer");
   MI_CHECK_ARG(n_ranks >= 1 && n_pos_global >= 1, "mi_merge_partials: bad sizes");
   MI_CHECK_ARG(estimator == MI_DV || estimator == MI_INFONCE, "mi_merge_partials: unknown estimator %d", estimator);
-  hipLaunchKernelGGL(merge_records_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, partials, n_ranks, n_pos_global,
-                     estimator, loss_out, stats);
+  {
+    ProfScope prof_("merge_records_kernel", (hipStream_t)stream);
+    hipLaunchKernelGGL(merge_records_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, partials, n_ranks, n_pos_global,
+                       estimator, loss_out, stats);
+  }
   MI_LAUNCH_CHECK("merge_records_kernel");
   return MI_OK;
 }

@@ -27,6 +27,22 @@ int hip_fail(hipError_t e, const char* what);
     if (e__ != hipSuccess) return ::mi::hip_fail(e__, what);    \
   } while (0)
 
+// Optional per-kernel timing with HIP events on the launch stream (mi_profile_begin / mi_profile_end); off by default,
+// one branch per launch when off.
+bool profile_enabled();
+void profile_push(const char* name, hipStream_t st, bool begin);
+struct ProfScope {
+  const char* name;
+  hipStream_t st;
+  bool on;
+  ProfScope(const char* n, hipStream_t s) : name(n), st(s), on(profile_enabled()) {
+    if (on) profile_push(name, st, true);
+  }
+  ~ProfScope() {
+    if (on) profile_push(name, st, false);
+  }
+};
+
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 // Bump allocator over the caller's workspace (never allocates).

@@ -1,25 +1,40 @@
 // Fused concat-MLP critic (the reference's mi_discriminator): host orchestration + C ABI.
 //   reference call site: mutual_info_img_txt/main_utils.py:220-226
-//   forward : U = X W1x^T, V = Y W1y^T + b1 (fp32 MFMA GEMMs) -> concat_fwd_kernel (scores + sign bits)
+//   forward : U = X W1x^T, V = Y W1y^T + b1 (fp32 MFMA GEMMs) -> concat_fwd_kernel (scores + sign-bit images)
 //             -> masked log-sum-exp over S (HBM-bound) -> stats, loss
-//   backward: see mi_concat_bwd.h
+//   backward: prep (w3*W2 permuted copy) -> duv kernel (dU, dV slabs) -> dw2 kernel (D slabs) -> db2 kernel ->
+//             slab reductions / finish -> dX = dU W1x, dY = dV W1y, dW1 = [dU^T X | dV^T Y], db1 = colsum(dV)
+#include "mi_concat_bwd.h"
 #include "mi_concat_fwd.h"
 #include "mi_gemm.h"
 
 namespace mi {
 
-// kernels defined in mi_bound.hip
+// kernel defined in mi_bound.hip
 __global__ void matrix_partials_kernel(const float*, const int64_t*, const int64_t*, int64_t, int64_t, int64_t, Partial*);
 
 constexpr int kMatrixPartialBlocks = 2048;
 
 struct ConcatPlan {
+  // forward
   float* u;
   float* v;
   bf16_t* w2bf;
   Partial* partials;
   unsigned long long* bitsP;
   unsigned* bitsN;
+  // backward
+  void* w2wp;
+  float* du_slab;
+  float* dv_slab;
+  float* du;
+  float* dv;
+  float* d_slab;
+  float* m_slab;
+  float* g_sum;
+  int n_jsplit, cols_per_split, n_iblk;
+  int n_dsplit, rows_per_dsplit;
+  int n_msplit, rows_per_msplit;
   size_t bytes;
 };
 
@@ -33,6 +48,32 @@ static ConcatPlan plan_concat(Workspace& ws, int64_t br, int64_t b, int64_t h1, 
   if (need_grad) {
     p.bitsP = ws.take<unsigned long long>(br * b * (h2 / 64));
     p.bitsN = ws.take<unsigned>(br * ((b + 31) / 32) * h2);
+    const int kc = (precision == MI_PREC_BF16) ? DuvCfg<bf16_t>::KC : DuvCfg<float>::KC;
+    const int64_t n_kc = (h1 + kc - 1) / kc;
+    p.n_iblk = (int)((br + kDuvTI - 1) / kDuvTI);
+    int64_t js = (512 + n_kc * p.n_iblk - 1) / (n_kc * p.n_iblk);
+    if (js < 1) js = 1;
+    if (js > 8) js = 8;
+    int64_t cps = (b + js - 1) / js;
+    cps = (cps + kDuvTJ - 1) / kDuvTJ * kDuvTJ;
+    p.cols_per_split = (int)cps;
+    p.n_jsplit = (int)((b + cps - 1) / cps);
+    int64_t rps = (br + 31) / 32;
+    if (rps < 16) rps = 16;
+    p.rows_per_dsplit = (int)rps;
+    p.n_dsplit = (int)((br + rps - 1) / rps);
+    int64_t rpm = (br + 255) / 256;
+    p.rows_per_msplit = (int)rpm;
+    p.n_msplit = (int)((br + rpm - 1) / rpm);
+    if (precision == MI_PREC_BF16) p.w2wp = ws.take<bf16_t>(h1 * h2);
+    else p.w2wp = ws.take<float>(h1 * h2);
+    p.du_slab = ws.take<float>((int64_t)p.n_jsplit * br * h1);
+    p.dv_slab = ws.take<float>((int64_t)p.n_iblk * b * h1);
+    p.du = ws.take<float>(br * h1);
+    p.dv = ws.take<float>(b * h1);
+    p.d_slab = ws.take<float>((int64_t)p.n_dsplit * h2 * h1);
+    p.m_slab = ws.take<float>((int64_t)p.n_msplit * h2);
+    p.g_sum = ws.take<float>(p.n_msplit);
   }
   p.bytes = ws.off;
   return p;
@@ -49,8 +90,8 @@ static int check_concat_shape(const char* fn, int64_t br, int64_t b, int64_t row
   MI_CHECK_ARG(row_offset >= 0 && row_offset + br <= b, "%s: row block outside [0, b)", fn);
   MI_CHECK_ARG(dx >= 1 && dy >= 1, "%s: embedding widths must be >= 1", fn);
   MI_CHECK_ARG(precision == MI_PREC_F32 || precision == MI_PREC_BF16, "%s: unknown precision %d", fn, precision);
-  if (h1 < 64 || h1 % 64 != 0 || h2 < 256 || h2 % 256 != 0) {
-    set_error("%s: the fused kernels need h1 %% 64 == 0 and h2 %% 256 == 0 (got h1=%lld, h2=%lld)", fn, (long long)h1,
+  if (h1 < 64 || h1 % 64 != 0 || h2 < 256 || h2 % 256 != 0 || h2 > 512) {
+    set_error("%s: the fused kernels need h1 %% 64 == 0 and h2 in {256, 512} (got h1=%lld, h2=%lld)", fn, (long long)h1,
               (long long)h2);
     return MI_ESHAPE;
   }
@@ -66,9 +107,111 @@ static int launch_concat_fwd(const float* u, const float* v, const OpT* w2, cons
                                      (int)smem);
   if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(concat_fwd_kernel)");
   dim3 grid((unsigned)((b + kFwdTJ - 1) / kFwdTJ), (unsigned)((br + kFwdTI - 1) / kFwdTI));
-  hipLaunchKernelGGL(concat_fwd_kernel<OpT>, grid, dim3(512), smem, st, u, v, w2, b2, w3, b3, br, b, h1, h2, scores,
-                     bitsP, bitsN);
+  {
+    ProfScope prof_("concat_fwd_kernel", st);
+    hipLaunchKernelGGL(concat_fwd_kernel<OpT>, grid, dim3(512), smem, st, u, v, w2, b2, w3, b3, br, b, h1, h2, scores,
+                       bitsP, bitsN);
+  }
   MI_LAUNCH_CHECK("concat_fwd_kernel");
+  return MI_OK;
+}
+
+template <typename OpT>
+static int concat_bwd_impl(const float* x, const float* y, const float* w1, const float* w2, const float* b2,
+                           const float* w3, const int64_t* sid_rows, const int64_t* sid_cols, int64_t br, int64_t b,
+                           int64_t row_offset, int64_t dx, int64_t dy, int h1, int h2, const mi_stats* stats,
+                           const float* grad_out, const float* scores, float* grad_x, float* grad_y, float* grad_w1,
+                           float* grad_b1, float* grad_w2, float* grad_b2, float* grad_w3, float* grad_b3,
+                           const ConcatPlan& p, hipStream_t st) {
+  using DC = DuvCfg<OpT>;
+  OpT* w2wp = (OpT*)p.w2wp;
+  {
+    ProfScope prof_("prep_w2w_kernel", st);
+    hipLaunchKernelGGL(prep_w2w_kernel<OpT>, dim3(512), dim3(256), 0, st, w2, w3, h1, h2, w2wp);
+  }
+  MI_LAUNCH_CHECK("prep_w2w_kernel");
+
+  // ---- dU / dV --------------------------------------------------------------------------------------------------
+  {
+    const int ldw = h2 + DC::PADW;
+    size_t smem = (((size_t)DC::KC * ldw * sizeof(OpT)) + 15) & ~(size_t)15;
+    smem += 256 * sizeof(bf16x8) + kDuvTI * kDuvTJ * sizeof(float) + kDuvTJ * DC::KC * sizeof(float) +
+            4 * kDuvTJ * DC::KC * sizeof(float);
+    hipError_t e = hipFuncSetAttribute((const void*)concat_bwd_duv_kernel<OpT>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(concat_bwd_duv_kernel)");
+    dim3 grid((unsigned)((h1 + DC::KC - 1) / DC::KC), (unsigned)p.n_iblk, (unsigned)p.n_jsplit);
+    {
+      ProfScope prof_("concat_bwd_duv_kernel", st);
+      hipLaunchKernelGGL(concat_bwd_duv_kernel<OpT>, grid, dim3(512), smem, st, (const float*)p.u, (const float*)p.v,
+                         (const OpT*)w2wp, (const unsigned long long*)p.bitsP, scores, sid_rows, sid_cols, stats,
+                         grad_out, br, b, row_offset, h1, h2, p.cols_per_split, p.du_slab, p.dv_slab);
+    }
+    MI_LAUNCH_CHECK("concat_bwd_duv_kernel");
+    {
+      ProfScope prof_("slab_reduce_kernel", st);
+      hipLaunchKernelGGL(slab_reduce_kernel, dim3(1024), dim3(256), 0, st, (const float*)p.du_slab, p.n_jsplit, br,
+                         (int64_t)h1, p.du);
+      hipLaunchKernelGGL(slab_reduce_kernel, dim3(1024), dim3(256), 0, st, (const float*)p.dv_slab, p.n_iblk, b,
+                         (int64_t)h1, p.dv);
+    }
+    MI_LAUNCH_CHECK("slab_reduce_kernel");
+  }
+
+  // ---- D = sum_p M g H1  ->  dW2, dW3, db2, db3 --------------------------------------------------------------------
+  {
+    const size_t smem = (256 * 36 + kDw2IB * 32) * sizeof(float) + 256 * sizeof(bf16x8);
+    hipError_t e = hipFuncSetAttribute((const void*)concat_bwd_dw2_kernel<OpT>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(concat_bwd_dw2_kernel)");
+    dim3 grid((unsigned)((h1 + 255) / 256), (unsigned)(h2 / 256), (unsigned)p.n_dsplit);
+    {
+      ProfScope prof_("concat_bwd_dw2_kernel", st);
+      hipLaunchKernelGGL(concat_bwd_dw2_kernel<OpT>, grid, dim3(512), smem, st, (const float*)p.u, (const float*)p.v,
+                         (const unsigned*)p.bitsN, scores, sid_rows, sid_cols, stats, grad_out, br, b, row_offset, h1,
+                         h2, p.rows_per_dsplit, p.d_slab);
+    }
+    MI_LAUNCH_CHECK("concat_bwd_dw2_kernel");
+    const size_t smem2 = (size_t)((b + 31) / 32) * 32 * sizeof(float);
+    e = hipFuncSetAttribute((const void*)concat_bwd_db2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)smem2);
+    if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(concat_bwd_db2_kernel)");
+    {
+      ProfScope prof_("concat_bwd_db2_kernel", st);
+      hipLaunchKernelGGL(concat_bwd_db2_kernel, dim3((unsigned)p.n_msplit), dim3(512), smem2, st,
+                         (const unsigned*)p.bitsN, scores, sid_rows, sid_cols, stats, grad_out, br, b, row_offset, h2,
+                         p.rows_per_msplit, p.m_slab, p.g_sum);
+    }
+    MI_LAUNCH_CHECK("concat_bwd_db2_kernel");
+    {
+      ProfScope prof_("concat_bwd_finish_w2_kernel", st);
+      hipLaunchKernelGGL(concat_bwd_finish_w2_kernel, dim3((unsigned)h2), dim3(256), 0, st, (const float*)p.d_slab,
+                         p.n_dsplit, (const float*)p.m_slab, (const float*)p.g_sum, p.n_msplit, w2, b2, w3, h1, h2,
+                         grad_w2, grad_w3, grad_b2, grad_b3);
+    }
+    MI_LAUNCH_CHECK("concat_bwd_finish_w2_kernel");
+  }
+
+  // ---- first layer: exact fp32 GEMMs (< 1 % of the flops) ------------------------------------------------------------
+  const int64_t d = dx + dy;
+  int rc = launch_gemm<float>(make_operand((const float*)p.du, h1, 1), make_operand(w1, 1, d), br, dx, h1,
+                              EpiStore{grad_x, dx, nullptr, 1.0f, 0}, st, "concat dX = dU W1x");
+  if (rc) return rc;
+  rc = launch_gemm<float>(make_operand((const float*)p.dv, h1, 1), make_operand(w1 + dx, 1, d), b, dy, h1,
+                          EpiStore{grad_y, dy, nullptr, 1.0f, 0}, st, "concat dY = dV W1y");
+  if (rc) return rc;
+  rc = launch_gemm<float>(make_operand((const float*)p.du, 1, h1), make_operand(x, 1, dx), h1, dx, br,
+                          EpiStore{grad_w1, d, nullptr, 1.0f, 0}, st, "concat dW1x = dU^T X");
+  if (rc) return rc;
+  rc = launch_gemm<float>(make_operand((const float*)p.dv, 1, h1), make_operand(y, 1, dy), h1, dy, b,
+                          EpiStore{grad_w1 + dx, d, nullptr, 1.0f, 0}, st, "concat dW1y = dV^T Y");
+  if (rc) return rc;
+  {
+    ProfScope prof_("colsum_kernel", st);
+    hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)((h1 + 63) / 64)), dim3(64), 0, st, (const float*)p.dv, b,
+                       (int64_t)h1, grad_b1);
+  }
+  MI_LAUNCH_CHECK("colsum_kernel");
   return MI_OK;
 }
 
@@ -114,7 +257,10 @@ int mi_concat_mlp_fwd(const float* x, const float* y, const float* w1, const flo
   unsigned long long* bitsP = need_grad ? p.bitsP : nullptr;
   unsigned* bitsN = need_grad ? p.bitsN : nullptr;
   if (precision == MI_PREC_BF16) {
-    hipLaunchKernelGGL(f32_to_bf16_kernel, dim3(512), dim3(256), 0, st, w2, p.w2bf, h1 * h2);
+    {
+      ProfScope prof_("f32_to_bf16_kernel", st);
+      hipLaunchKernelGGL(f32_to_bf16_kernel, dim3(512), dim3(256), 0, st, w2, p.w2bf, h1 * h2);
+    }
     MI_LAUNCH_CHECK("f32_to_bf16_kernel");
     rc = launch_concat_fwd<bf16_t>(p.u, p.v, p.w2bf, b2, w3, b3, b_rows, b, (int)h1, (int)h2, scores_out, bitsP, bitsN,
                                    st);
@@ -123,18 +269,44 @@ int mi_concat_mlp_fwd(const float* x, const float* y, const float* w1, const flo
   }
   if (rc) return rc;
   const int grid = (int)(b_rows < kMatrixPartialBlocks ? b_rows : kMatrixPartialBlocks);
-  hipLaunchKernelGGL(matrix_partials_kernel, dim3(grid), dim3(256), 0, st, (const float*)scores_out, sid_rows, sid_cols,
-                     b_rows, b, row_offset, p.partials);
+  {
+    ProfScope prof_("matrix_partials_kernel", st);
+    hipLaunchKernelGGL(matrix_partials_kernel, dim3(grid), dim3(256), 0, st, (const float*)scores_out, sid_rows,
+                       sid_cols, b_rows, b, row_offset, p.partials);
+  }
   MI_LAUNCH_CHECK("matrix_partials_kernel");
   return launch_finalize(p.partials, grid, b, estimator, loss_out, stats, partials_out, st);
 }
 
-int mi_concat_mlp_bwd(const float*, const float*, const float*, const float*, const float*, const float*, const float*,
-                      const float*, const int64_t*, const int64_t*, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t,
-                      int64_t, int, const mi_stats*, const float*, const float*, float*, float*, float*, float*, float*,
-                      float*, float*, float*, void*, size_t, void*) {
-  set_error("mi_concat_mlp_bwd: not built yet");
-  return MI_ESHAPE;
+int mi_concat_mlp_bwd(const float* x, const float* y, const float* w1, const float* b1, const float* w2, const float* b2,
+                      const float* w3, const float* b3, const int64_t* sid_rows, const int64_t* sid_cols, int64_t b_rows,
+                      int64_t b, int64_t row_offset, int64_t d_img, int64_t d_txt, int64_t h1, int64_t h2, int precision,
+                      const mi_stats* stats, const float* grad_out, const float* scores, float* grad_x, float* grad_y,
+                      float* grad_w1, float* grad_b1, float* grad_w2, float* grad_b2, float* grad_w3, float* grad_b3,
+                      void* workspace, size_t workspace_bytes, void* stream) {
+  (void)b1;
+  (void)b3;
+  MI_CHECK_ARG(x && y && w1 && w2 && b2 && w3 && sid_rows && sid_cols && stats && scores && grad_x && grad_y &&
+                   grad_w1 && grad_b1 && grad_w2 && grad_b2 && grad_w3 && grad_b3 && workspace,
+               "mi_concat_mlp_bwd: null pointer");
+  int rc = check_concat_shape("mi_concat_mlp_bwd", b_rows, b, row_offset, d_img, d_txt, h1, h2, precision);
+  if (rc) return rc;
+  Workspace ws(workspace, workspace_bytes);
+  ConcatPlan p = plan_concat(ws, b_rows, b, h1, h2, precision, 1);
+  if (!ws.ok()) {
+    set_error("mi_concat_mlp_bwd: workspace too small (%zu < %zu): pass the workspace of the forward call made with "
+              "need_grad = 1",
+              workspace_bytes, ws.off);
+    return MI_EWORKSPACE;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  if (precision == MI_PREC_BF16)
+    return concat_bwd_impl<bf16_t>(x, y, w1, w2, b2, w3, sid_rows, sid_cols, b_rows, b, row_offset, d_img, d_txt,
+                                   (int)h1, (int)h2, stats, grad_out, scores, grad_x, grad_y, grad_w1, grad_b1, grad_w2,
+                                   grad_b2, grad_w3, grad_b3, p, st);
+  return concat_bwd_impl<float>(x, y, w1, w2, b2, w3, sid_rows, sid_cols, b_rows, b, row_offset, d_img, d_txt, (int)h1,
+                                (int)h2, stats, grad_out, scores, grad_x, grad_y, grad_w1, grad_b1, grad_w2, grad_b2,
+                                grad_w3, grad_b3, p, st);
 }
 
 }  // extern "C"

@@ -1,0 +1,569 @@
+// Fused concat-MLP critic, backward, from the sign-bit images and scores saved by the forward.
+//
+// With g_p = d loss / d score of pair p = (i, j), M[p, n] = 1[Z2[p, n] > 0] (saved bits) and H1[p, k] = relu(U_i[k] + V_j[k]):
+//   dZ2[p, n] = g_p w3[n] M[p, n]
+//   dU_i[k]   = sum_j g_p 1[U_i[k] + V_j[k] > 0] E[p, k],   E[p, k] = sum_n M[p, n] (w3[n] W2[n, k])     ("duv" kernel)
+//   dV_j[k]   = sum_i  (same summand)
+//   D[n, k]   = sum_p M[p, n] g_p H1[p, k];   dW2 = w3[n] D[n, k];   dW3[n] = sum_k W2[n, k] D[n, k] + b2[n] m[n];
+//   db2[n] = w3[n] m[n],  m[n] = sum_p g_p M[p, n];   db3 = sum_p g_p                                     ("dw2" kernel)
+// Both big contractions run on MFMA with one operand expanded on the fly from the bit images (a 256-entry LDS table
+// turns a byte of sign bits into an 8-element bf16 fragment of {0, 2}; the factor 2 is folded into g) and the other
+// either LDS-resident (duv: a [128 k x H2] slice of w3*W2 stays in LDS for the whole column sweep) or generated in
+// registers (dw2: g_p relu(U_i + V_j)).  All cross-workgroup sums go through slabs reduced in a fixed order.
+#pragma once
+#include "mi_common.h"
+#include "mi_concat_fwd.h"
+
+namespace mi {
+
+// d loss / d score of pair (global row gi, column gj) times grad_out; 0 for dropped / out-of-range pairs
+__device__ __forceinline__ float pair_grad(float score, int64_t gi, int64_t gj, int64_t sid_i, int64_t sid_j, float lse,
+                                           float go, float gpos) {
+  const int kind = pair_kind(gi, gj, sid_i, sid_j);
+  if (kind == 1) return gpos;
+  if (kind == 2) return go * expf(score - lse);
+  return 0.0f;
+}
+
+// n index of slot m of the permuted hidden-unit order used by bitsP / W2wP:
+//   m = ((pw * 2 + h) * 64 + q), pw = pass * 2 + wn, q = 16 a + r  ->  n = 128 pw + 32 a + (r & 3) + 8 (r >> 2) + 4 h
+__host__ __device__ __forceinline__ int slot_to_n(int m) {
+  const int q = m & 63, h = (m >> 6) & 1, pw = m >> 7;
+  const int a = q >> 4, r = q & 15;
+  return 128 * pw + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * h;
+}
+
+// W2wP[k][m] = W2[n(m)][k] * w3[n(m)]   (transposed, permuted, scaled copy; [H1][H2])
+template <typename OpT>
+__global__ void prep_w2w_kernel(const float* __restrict__ w2, const float* __restrict__ w3, int H1, int H2,
+                                OpT* __restrict__ out) {
+  const int64_t total = (int64_t)H1 * H2;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+    const int k = (int)(e / H2), m = (int)(e % H2);
+    const int n = slot_to_n(m);
+    out[e] = (OpT)(w2[(int64_t)n * H1 + k] * w3[n]);
+  }
+}
+
+// ================================================================================================= duv kernel
+template <typename OpT>
+struct DuvCfg;
+template <>
+struct DuvCfg<bf16_t> {
+  static constexpr int KC = 128;  // k columns per workgroup
+  static constexpr int NT = 4;    // 32-wide column tiles per wave
+  static constexpr int PADW = 8;  // row pad of the LDS weight slice in elements (1040-byte rows: conflict-free b128)
+};
+template <>
+struct DuvCfg<float> {
+  static constexpr int KC = 32;
+  static constexpr int NT = 1;
+  static constexpr int PADW = 1;
+};
+
+constexpr int kDuvTI = 64;  // image rows per workgroup
+constexpr int kDuvTJ = 8;   // text columns per step
+
+template <typename OpT>
+__global__ __launch_bounds__(512) void concat_bwd_duv_kernel(
+    const float* __restrict__ U, const float* __restrict__ V, const OpT* __restrict__ W2wP,
+    const unsigned long long* __restrict__ bitsP, const float* __restrict__ S, const int64_t* __restrict__ sid_rows,
+    const int64_t* __restrict__ sid_cols, const mi_stats* __restrict__ stats, const float* __restrict__ grad_out,
+    int64_t b_rows, int64_t b, int64_t row_offset, int H1, int H2, int cols_per_split,
+    float* __restrict__ dUslab /* [n_jsplit][b_rows][H1] */, float* __restrict__ dVslab /* [n_iblk][b][H1] */) {
+  using Cfg = DuvCfg<OpT>;
+  constexpr int KC = Cfg::KC, NT = Cfg::NT;
+  constexpr bool kBf16 = sizeof(OpT) == 2;
+  const int LDW = H2 + Cfg::PADW;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  OpT* wt = reinterpret_cast<OpT*>(smem_raw);                                   // [KC][LDW]
+  size_t off = (((size_t)KC * LDW * sizeof(OpT)) + 15) & ~(size_t)15;
+  bf16x8* lut = reinterpret_cast<bf16x8*>(smem_raw + off);                      // [256] (bf16 only)
+  off += 256 * sizeof(bf16x8);
+  float* gs = reinterpret_cast<float*>(smem_raw + off);                         // [64][8]
+  off += kDuvTI * kDuvTJ * sizeof(float);
+  float* vneg = reinterpret_cast<float*>(smem_raw + off);                       // [8][KC]
+  off += kDuvTJ * KC * sizeof(float);
+  float* dvred = reinterpret_cast<float*>(smem_raw + off);                      // [4][8][KC]
+
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int c = lane & 31, h = lane >> 5;
+  const int kc0 = blockIdx.x * KC;
+  const int64_t i0 = (int64_t)blockIdx.y * kDuvTI;
+  const int64_t jlo = (int64_t)blockIdx.z * cols_per_split;
+  int64_t jhi = jlo + cols_per_split;
+  if (jhi > b) jhi = b;
+  const int wpp = H2 / 64, hw = wpp / 2;  // 64-bit words per pair, per lane half
+
+  const float go = grad_out ? grad_out[0] : 1.0f;
+  const float lse = stats->lse;
+  const float gpos = -go / (float)stats->n_pos;
+  const float gscale = kBf16 ? 0.5f : 1.0f;  // the bf16 fragment table holds 2.0 for a set bit
+
+  // ---- one-time setup: weight slice, table, U registers ----------------------------------------------------------
+  {
+    const int vec = 16 / (int)sizeof(OpT);          // elements per 16-byte vector
+    const int vec_per_row = H2 / vec;
+    for (int e = tid; e < KC * vec_per_row; e += 512) {
+      const int row = e / vec_per_row, v = e % vec_per_row;
+      u32x4 x = {0u, 0u, 0u, 0u};
+      if (kc0 + row < H1) x = *reinterpret_cast<const u32x4*>(W2wP + (int64_t)(kc0 + row) * H2 + v * vec);
+      if constexpr (kBf16) {
+        *reinterpret_cast<u32x4*>(&wt[row * LDW + v * vec]) = x;
+      } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const unsigned bits = x[q];
+          reinterpret_cast<float*>(wt)[row * LDW + v * 4 + q] = __builtin_bit_cast(float, bits);
+        }
+      }
+    }
+    if constexpr (kBf16) {
+      if (tid < 256) {
+        bf16x8 f;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) f[q] = (bf16_t)(((tid >> q) & 1) ? 2.0f : 0.0f);
+        lut[tid] = f;
+      }
+    }
+  }
+  float ureg[2][4][NT];
+  float duacc[2][4][NT];
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int is = 0; is < 4; ++is) {
+      int64_t li = i0 + 8 * wave + 4 * m + is;
+      if (li >= b_rows) li = b_rows - 1;
+#pragma unroll
+      for (int ct = 0; ct < NT; ++ct) {
+        const int k = kc0 + 32 * ct + c;
+        ureg[m][is][ct] = (k < H1) ? U[li * H1 + k] : 0.0f;
+        duacc[m][is][ct] = 0.0f;
+      }
+    }
+  __syncthreads();
+
+  for (int64_t j = jlo; j < jhi; j += kDuvTJ) {
+    // ---- (a) g tile and -V tile ---------------------------------------------------------------------------------
+    {
+      const int il = tid >> 3, jl = tid & 7;
+      const int64_t li = i0 + il, gj = j + jl;
+      float g = 0.0f;
+      if (li < b_rows && gj < jhi)
+        g = gscale * pair_grad(S[li * b + gj], row_offset + li, gj, sid_rows[li], sid_cols[gj], lse, go, gpos);
+      gs[il * kDuvTJ + jl] = g;
+      for (int e = tid; e < kDuvTJ * KC; e += 512) {
+        const int jl2 = e / KC, kk = e % KC;
+        int64_t gj2 = j + jl2;
+        if (gj2 >= b) gj2 = b - 1;
+        vneg[e] = (kc0 + kk < H1) ? -V[gj2 * H1 + kc0 + kk] : 0.0f;
+      }
+    }
+    __syncthreads();
+
+    // ---- (b) sign words of this lane's two pairs ----------------------------------------------------------------
+    unsigned long long words[2][4];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      const int64_t li = i0 + 8 * wave + 4 * m + (c >> 3), gj = j + (c & 7);
+      const bool ok = li < b_rows && gj < jhi;
+#pragma unroll
+      for (int pw = 0; pw < 4; ++pw)
+        words[m][pw] = (ok && pw < hw) ? bitsP[(li * b + gj) * wpp + h * hw + pw] : 0ull;
+    }
+    float vn[4][NT];
+#pragma unroll
+    for (int jq = 0; jq < 4; ++jq)
+#pragma unroll
+      for (int ct = 0; ct < NT; ++ct) vn[jq][ct] = vneg[(jq + 4 * h) * KC + 32 * ct + c];
+
+    // ---- (c) E[pair, k] = sum_n M[pair, n] W2w[n, k] on MFMA -------------------------------------------------------
+    f32x16 acc[2][NT];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int ct = 0; ct < NT; ++ct)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[m][ct][r] = 0.0f;
+
+#pragma unroll
+    for (int pw = 0; pw < 4; ++pw) {
+      if (pw < hw) {
+        if constexpr (kBf16) {
+#pragma unroll
+          for (int s = 0; s < 8; ++s) {
+            bf16x8 af[2];
+#pragma unroll
+            for (int m = 0; m < 2; ++m) af[m] = lut[(unsigned)(words[m][pw] >> (8 * s)) & 0xFFu];
+#pragma unroll
+            for (int ct = 0; ct < NT; ++ct) {
+              const bf16x8 bfr = *reinterpret_cast<const bf16x8*>(&wt[(32 * ct + c) * LDW + (pw * 2 + h) * 64 + 8 * s]);
+#pragma unroll
+              for (int m = 0; m < 2; ++m)
+                acc[m][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[m], bfr, acc[m][ct], 0, 0, 0);
+            }
+          }
+        } else {
+          for (int s = 0; s < 64; ++s) {
+            float af[2];
+#pragma unroll
+            for (int m = 0; m < 2; ++m) af[m] = ((words[m][pw] >> s) & 1ull) ? 1.0f : 0.0f;
+#pragma unroll
+            for (int ct = 0; ct < NT; ++ct) {
+              const float bfr = reinterpret_cast<const float*>(wt)[(32 * ct + c) * LDW + (pw * 2 + h) * 64 + s];
+#pragma unroll
+              for (int m = 0; m < 2; ++m)
+                acc[m][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[m], bfr, acc[m][ct], 0, 0, 0);
+            }
+          }
+        }
+      }
+    }
+
+    // ---- (d) epilogue: relu' of layer 1, g, row / column sums -------------------------------------------------------
+    float dvp[4][NT];
+#pragma unroll
+    for (int jq = 0; jq < 4; ++jq)
+#pragma unroll
+      for (int ct = 0; ct < NT; ++ct) dvp[jq][ct] = 0.0f;
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int is = r >> 2, jq = r & 3;  // row rho = jq + 8 is + 4 h  ->  local row 4m + is, local column jq + 4h
+        const float g = gs[(8 * wave + 4 * m + is) * kDuvTJ + jq + 4 * h];
+#pragma unroll
+        for (int ct = 0; ct < NT; ++ct) {
+          const float e = (ureg[m][is][ct] > vn[jq][ct]) ? acc[m][ct][r] : 0.0f;
+          duacc[m][is][ct] += g * e;
+          dvp[jq][ct] += g * e;
+        }
+      }
+
+    // ---- (e) dV: deterministic cross-wave reduction (waves w and w+4 share a slot, in that order) -----------------
+    if (wave < 4) {
+#pragma unroll
+      for (int jq = 0; jq < 4; ++jq)
+#pragma unroll
+        for (int ct = 0; ct < NT; ++ct) dvred[(wave * kDuvTJ + jq + 4 * h) * KC + 32 * ct + c] = dvp[jq][ct];
+    }
+    __syncthreads();
+    if (wave >= 4) {
+#pragma unroll
+      for (int jq = 0; jq < 4; ++jq)
+#pragma unroll
+        for (int ct = 0; ct < NT; ++ct) dvred[((wave - 4) * kDuvTJ + jq + 4 * h) * KC + 32 * ct + c] += dvp[jq][ct];
+    }
+    __syncthreads();
+    for (int e = tid; e < kDuvTJ * KC; e += 512) {
+      const int jl = e / KC, kk = e % KC;
+      const int64_t gj = j + jl;
+      if (gj < jhi && kc0 + kk < H1) {
+        const float v = ((dvred[(0 * kDuvTJ + jl) * KC + kk] + dvred[(1 * kDuvTJ + jl) * KC + kk]) +
+                         dvred[(2 * kDuvTJ + jl) * KC + kk]) + dvred[(3 * kDuvTJ + jl) * KC + kk];
+        dVslab[((int64_t)blockIdx.y * b + gj) * H1 + kc0 + kk] = v;
+      }
+    }
+    __syncthreads();  // gs / vneg / dvred are rewritten by the next step
+  }
+
+  // ---- dU of this (row block, k chunk, column split) -----------------------------------------------------------------
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int is = 0; is < 4; ++is) {
+      const int64_t li = i0 + 8 * wave + 4 * m + is;
+#pragma unroll
+      for (int ct = 0; ct < NT; ++ct) {
+        const float v = duacc[m][is][ct] + __shfl_xor(duacc[m][is][ct], 32);
+        if (h == 0 && li < b_rows && kc0 + 32 * ct + c < H1)
+          dUslab[((int64_t)blockIdx.z * b_rows + li) * H1 + kc0 + 32 * ct + c] = v;
+      }
+    }
+}
+
+// ================================================================================================= dw2 kernel
+constexpr int kDw2IB = 128;  // image rows per g batch
+
+// D slab [n_split][H2][H1]; workgroup = (k block of 256, n block of 256, pair split); wave (wn, wk): 128 n x 64 k.
+template <typename OpT>
+__global__ __launch_bounds__(512) void concat_bwd_dw2_kernel(
+    const float* __restrict__ U, const float* __restrict__ V, const unsigned* __restrict__ bitsN,
+    const float* __restrict__ S, const int64_t* __restrict__ sid_rows, const int64_t* __restrict__ sid_cols,
+    const mi_stats* __restrict__ stats, const float* __restrict__ grad_out, int64_t b_rows, int64_t b,
+    int64_t row_offset, int H1, int H2, int rows_per_split, float* __restrict__ Dslab) {
+  constexpr bool kBf16 = sizeof(OpT) == 2;
+  constexpr int LDV = 36;  // floats per k row of the transposed V tile (32 columns + pad: conflict-free b128)
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float* vt = reinterpret_cast<float*>(smem_raw);                       // [256 k][LDV]
+  float* gs = vt + 256 * LDV;                                           // [kDw2IB][32]
+  bf16x8* lut = reinterpret_cast<bf16x8*>(gs + kDw2IB * 32);            // [256]
+
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int wn = wave >> 2, wk = wave & 3;
+  const int c = lane & 31, h = lane >> 5;
+  const int kb0 = blockIdx.x * 256, nb0 = blockIdx.y * 256;
+  const int64_t ilo = (int64_t)blockIdx.z * rows_per_split;
+  int64_t ihi = ilo + rows_per_split;
+  if (ihi > b_rows) ihi = b_rows;
+  const int64_t JB = (b + 31) / 32;
+
+  const float go = grad_out ? grad_out[0] : 1.0f;
+  const float lse = stats->lse;
+  const float gpos = -go / (float)stats->n_pos;
+  const float gscale = kBf16 ? 0.5f : 1.0f;
+
+  if constexpr (kBf16) {
+    if (tid < 256) {
+      bf16x8 f;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) f[q] = (bf16_t)(((tid >> q) & 1) ? 2.0f : 0.0f);
+      lut[tid] = f;
+    }
+  }
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][t][r] = 0.0f;
+
+  const int kcol[2] = {kb0 + 64 * wk + c, kb0 + 64 * wk + 32 + c};
+  const bool kok[2] = {kcol[0] < H1, kcol[1] < H1};
+
+  for (int64_t jb = 0; jb < JB; ++jb) {
+    const int64_t j0 = jb * 32;
+    __syncthreads();  // previous column block's readers of vt / gs are done
+    // V tile transposed: vt[k][j] = V[j0 + j][kb0 + k]
+    for (int e = tid; e < 32 * 256; e += 512) {
+      const int jl = e >> 8, kk = e & 255;
+      int64_t gj = j0 + jl;
+      if (gj >= b) gj = b - 1;
+      vt[kk * LDV + jl] = (kb0 + kk < H1) ? V[gj * H1 + kb0 + kk] : 0.0f;
+    }
+    for (int64_t ib = ilo; ib < ihi; ib += kDw2IB) {
+      __syncthreads();  // vt visible (first batch); previous batch's readers of gs are done
+      for (int e = tid; e < kDw2IB * 32; e += 512) {
+        const int il = e >> 5, jl = e & 31;
+        const int64_t li = ib + il, gj = j0 + jl;
+        float g = 0.0f;
+        if (li < ihi && gj < b)
+          g = gscale * pair_grad(S[li * b + gj], row_offset + li, gj, sid_rows[li], sid_cols[gj], lse, go, gpos);
+        gs[e] = g;
+      }
+      __syncthreads();
+      const int n_i = (int)((ihi - ib) < kDw2IB ? (ihi - ib) : kDw2IB);
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {  // 16 columns per MFMA K step: this lane half takes columns 16 s + 8 h + [0, 8)
+        float vreg[2][8];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const f32x4 v0 = *reinterpret_cast<const f32x4*>(&vt[(64 * wk + 32 * t + c) * LDV + 16 * s + 8 * h]);
+          const f32x4 v1 = *reinterpret_cast<const f32x4*>(&vt[(64 * wk + 32 * t + c) * LDV + 16 * s + 8 * h + 4]);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            vreg[t][q] = v0[q];
+            vreg[t][4 + q] = v1[q];
+          }
+        }
+        // software prefetch of the next row's sign words and U values
+        unsigned wnext[4];
+        float unext[2];
+        {
+          const int64_t li = ib;
+#pragma unroll
+          for (int a = 0; a < 4; ++a) wnext[a] = bitsN[(li * JB + jb) * H2 + nb0 + 128 * wn + 32 * a + c];
+#pragma unroll
+          for (int t = 0; t < 2; ++t) unext[t] = kok[t] ? U[li * H1 + kcol[t]] : 0.0f;
+        }
+        for (int il = 0; il < n_i; ++il) {
+          unsigned wcur[4];
+          float ucur[2];
+#pragma unroll
+          for (int a = 0; a < 4; ++a) wcur[a] = wnext[a];
+#pragma unroll
+          for (int t = 0; t < 2; ++t) ucur[t] = unext[t];
+          if (il + 1 < n_i) {
+            const int64_t li = ib + il + 1;
+#pragma unroll
+            for (int a = 0; a < 4; ++a) wnext[a] = bitsN[(li * JB + jb) * H2 + nb0 + 128 * wn + 32 * a + c];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) unext[t] = kok[t] ? U[li * H1 + kcol[t]] : 0.0f;
+          }
+          const f32x4 g0 = *reinterpret_cast<const f32x4*>(&gs[il * 32 + 16 * s + 8 * h]);
+          const f32x4 g1 = *reinterpret_cast<const f32x4*>(&gs[il * 32 + 16 * s + 8 * h + 4]);
+          if constexpr (kBf16) {
+            bf16x8 hf[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                hf[t][q] = (bf16_t)(fmaxf(ucur[t] + vreg[t][q], 0.0f) * g0[q]);
+                hf[t][4 + q] = (bf16_t)(fmaxf(ucur[t] + vreg[t][4 + q], 0.0f) * g1[q]);
+              }
+            }
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+              const bf16x8 mf = lut[(wcur[a] >> (16 * s + 8 * h)) & 0xFFu];
+#pragma unroll
+              for (int t = 0; t < 2; ++t) acc[a][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(mf, hf[t], acc[a][t], 0, 0, 0);
+            }
+          } else {
+            // fp32 MFMA: K = 2 per instruction; lane half h takes column 16 s + 2 q + h of step q
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+              // columns of this step: h = 0 -> 16 s + 8*0 + q ... keep the bf16 slot order: slot (h, q) = column 16 s + 8 h + q
+              const float gq = (q < 4) ? g0[q] : g1[q - 4];
+              float hv[2];
+#pragma unroll
+              for (int t = 0; t < 2; ++t) hv[t] = fmaxf(ucur[t] + vreg[t][q], 0.0f) * gq;
+#pragma unroll
+              for (int a = 0; a < 4; ++a) {
+                const float mf = ((wcur[a] >> (16 * s + 8 * h + q)) & 1u) ? 1.0f : 0.0f;
+#pragma unroll
+                for (int t = 0; t < 2; ++t) acc[a][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(mf, hv[t], acc[a][t], 0, 0, 0);
+              }
+            }
+          }
+        }
+      }
+    }
+  }
+
+  // ---- store the partial D tile (rows n = registers, columns k = lanes) -------------------------------------------
+  float* out = Dslab + (int64_t)blockIdx.z * H2 * H1;
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int n = nb0 + 128 * wn + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (kok[t]) out[(int64_t)n * H1 + kcol[t]] = acc[a][t][r];
+      }
+}
+
+// ================================================================================================= small kernels
+// m[n] partial = sum over a slice of rows of g_p M[p, n]; also the slice's sum of g_p (db3).  One workgroup per row
+// slice, one thread per hidden unit n (512 threads -> H2 <= 512 per pass over n).
+__global__ __launch_bounds__(512) void concat_bwd_db2_kernel(const unsigned* __restrict__ bitsN,
+                                                             const float* __restrict__ S,
+                                                             const int64_t* __restrict__ sid_rows,
+                                                             const int64_t* __restrict__ sid_cols,
+                                                             const mi_stats* __restrict__ stats,
+                                                             const float* __restrict__ grad_out, int64_t b_rows, int64_t b,
+                                                             int64_t row_offset, int H2, int rows_per_split,
+                                                             float* __restrict__ mslab /* [n_split][H2] */,
+                                                             float* __restrict__ gsum /* [n_split] */) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float* grow = reinterpret_cast<float*>(smem_raw);  // [32 * JB]
+  __shared__ float red[8];
+  const int tid = threadIdx.x;
+  const int64_t JB = (b + 31) / 32;
+  const int64_t ilo = (int64_t)blockIdx.x * rows_per_split;
+  int64_t ihi = ilo + rows_per_split;
+  if (ihi > b_rows) ihi = b_rows;
+  const float go = grad_out ? grad_out[0] : 1.0f;
+  const float lse = stats->lse;
+  const float gpos = -go / (float)stats->n_pos;
+  float gtot = 0.0f;
+  float macc[2] = {0.0f, 0.0f};  // hidden units tid and tid + 512
+  for (int64_t li = ilo; li < ihi; ++li) {
+    __syncthreads();
+    const int64_t si = sid_rows[li];
+    for (int64_t gj = tid; gj < JB * 32; gj += 512) {
+      float g = 0.0f;
+      if (gj < b) g = pair_grad(S[li * b + gj], row_offset + li, gj, si, sid_cols[gj], lse, go, gpos);
+      grow[gj] = g;
+      gtot += g;
+    }
+    __syncthreads();
+    for (int pass = 0; pass * 512 < H2; ++pass) {
+      const int n = pass * 512 + tid;
+      if (n < H2) {
+        float a = 0.0f;
+        for (int64_t jb = 0; jb < JB; ++jb) {
+          const unsigned w = bitsN[(li * JB + jb) * H2 + n];
+          const float* gr = grow + jb * 32;
+#pragma unroll
+          for (int q = 0; q < 32; ++q) a += ((w >> q) & 1u) ? gr[q] : 0.0f;
+        }
+        macc[pass & 1] += a;
+      }
+    }
+  }
+  for (int pass = 0; pass * 512 < H2 && pass < 2; ++pass) {
+    const int n = pass * 512 + tid;
+    if (n < H2) mslab[(int64_t)blockIdx.x * H2 + n] = macc[pass];
+  }
+  gtot = wave_sum(gtot);
+  if ((tid & 63) == 0) red[tid >> 6] = gtot;
+  __syncthreads();
+  if (tid == 0) {
+    float t = 0.0f;
+    for (int w = 0; w < 8; ++w) t += red[w];
+    gsum[blockIdx.x] = t;
+  }
+}
+
+// One workgroup per hidden unit n: D[n, :] = sum of slabs (fixed order); dW2[n, :] = w3[n] D; dW3[n], db2[n]; n == 0: db3.
+__global__ __launch_bounds__(256) void concat_bwd_finish_w2_kernel(const float* __restrict__ Dslab, int n_dsplit,
+                                                                   const float* __restrict__ mslab,
+                                                                   const float* __restrict__ gsum, int n_msplit,
+                                                                   const float* __restrict__ w2, const float* __restrict__ b2,
+                                                                   const float* __restrict__ w3, int H1, int H2,
+                                                                   float* __restrict__ dW2, float* __restrict__ dW3,
+                                                                   float* __restrict__ db2, float* __restrict__ db3) {
+  __shared__ float red[4];
+  const int n = blockIdx.x, tid = threadIdx.x;
+  const float w3n = w3[n];
+  float dot = 0.0f;
+  for (int k = tid; k < H1; k += 256) {
+    float d = 0.0f;
+    for (int s = 0; s < n_dsplit; ++s) d += Dslab[((int64_t)s * H2 + n) * H1 + k];
+    dW2[(int64_t)n * H1 + k] = w3n * d;
+    dot += w2[(int64_t)n * H1 + k] * d;
+  }
+  dot = wave_sum(dot);
+  if ((tid & 63) == 0) red[tid >> 6] = dot;
+  __syncthreads();
+  if (tid == 0) {
+    const float total = (red[0] + red[1]) + (red[2] + red[3]);
+    float m = 0.0f;
+    for (int s = 0; s < n_msplit; ++s) m += mslab[(int64_t)s * H2 + n];
+    dW3[n] = total + b2[n] * m;
+    db2[n] = w3n * m;
+    if (n == 0) {
+      float g = 0.0f;
+      for (int s = 0; s < n_msplit; ++s) g += gsum[s];
+      db3[0] = g;
+    }
+  }
+}
+
+// out[r, k] = sum_s slab[s][r][k]   (fixed order); optional column sums of the result are done by colsum_kernel
+__global__ void slab_reduce_kernel(const float* __restrict__ slab, int n_slab, int64_t rows, int64_t cols,
+                                   float* __restrict__ out) {
+  const int64_t total = rows * cols / 4;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+    f32x4 a = *reinterpret_cast<const f32x4*>(slab + 4 * e);
+    for (int s = 1; s < n_slab; ++s) a += *reinterpret_cast<const f32x4*>(slab + (int64_t)s * rows * cols + 4 * e);
+    *reinterpret_cast<f32x4*>(out + 4 * e) = a;
+  }
+}
+
+// out[k] = sum_r m[r, k]  (one thread per column, rows in order: deterministic)
+__global__ void colsum_kernel(const float* __restrict__ m, int64_t rows, int64_t cols, float* __restrict__ out) {
+  const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= cols) return;
+  float a = 0.0f;
+  for (int64_t r = 0; r < rows; ++r) a += m[r * cols + k];
+  out[k] = a;
+}
+
+}  // namespace mi

@@ -306,7 +306,10 @@ static inline int launch_gemm(const Operand<TA>& A, const Operand<TB>& B, int64_
                               const Epi& epi, hipStream_t st, const char* what) {
   if (M <= 0 || N <= 0) return MI_OK;
   dim3 grid((unsigned)((N + kTile - 1) / kTile), (unsigned)((M + kTile - 1) / kTile));
-  hipLaunchKernelGGL((gemm_nt_kernel<OpT, TA, TB, Epi>), grid, dim3(256), 0, st, A, B, M, N, K, epi);
+  {
+    ProfScope prof_(what, st);
+    hipLaunchKernelGGL((gemm_nt_kernel<OpT, TA, TB, Epi>), grid, dim3(256), 0, st, A, B, M, N, K, epi);
+  }
   MI_LAUNCH_CHECK(what);
   return MI_OK;
 }

@@ -198,10 +198,16 @@ static int run_count_scan(const int64_t* sid, int64_t b, Workspace& ws, int** co
     return MI_EWORKSPACE;
   }
   if (n_chunks > 0) {
-    hipLaunchKernelGGL(pairs_count_kernel, dim3((unsigned)n_chunks), dim3(kPBlock), 0, st, sid, b, n_entries, counts);
+    {
+      ProfScope prof_("pairs_count_kernel", st);
+      hipLaunchKernelGGL(pairs_count_kernel, dim3((unsigned)n_chunks), dim3(kPBlock), 0, st, sid, b, n_entries, counts);
+    }
     MI_LAUNCH_CHECK("pairs_count_kernel");
   }
-  hipLaunchKernelGGL(pairs_scan_kernel, dim3(1), dim3(kPBlock), 0, st, counts, n_chunks, b, offsets, nrows);
+  {
+    ProfScope prof_("pairs_scan_kernel", st);
+    hipLaunchKernelGGL(pairs_scan_kernel, dim3(1), dim3(kPBlock), 0, st, counts, n_chunks, b, offsets, nrows);
+  }
   MI_LAUNCH_CHECK("pairs_scan_kernel");
   *counts_out = counts;
   *offsets_out = offsets;
@@ -238,12 +244,18 @@ int mi_pair_index(const int64_t* sid, int64_t b, int32_t* pair_i, int32_t* pair_
   hipStream_t st = (hipStream_t)stream;
   int rc = run_count_scan(sid, b, ws, &counts, &offsets, &nrows, &n_chunks, st);
   if (rc != MI_OK) return rc;
-  hipLaunchKernelGGL(pairs_positive_kernel, dim3((unsigned)((b + 255) / 256)), dim3(256), 0, st, b, capacity, pair_i,
-                     pair_j);
+  {
+    ProfScope prof_("pairs_positive_kernel", st);
+    hipLaunchKernelGGL(pairs_positive_kernel, dim3((unsigned)((b + 255) / 256)), dim3(256), 0, st, b, capacity, pair_i,
+                       pair_j);
+  }
   MI_LAUNCH_CHECK("pairs_positive_kernel");
   if (n_chunks > 0) {
-    hipLaunchKernelGGL(pairs_emit_kernel, dim3((unsigned)n_chunks), dim3(kPBlock), 0, st, sid, b, b * (b - 1), offsets,
-                       pair_i, pair_j, capacity, rowpos);
+    {
+      ProfScope prof_("pairs_emit_kernel", st);
+      hipLaunchKernelGGL(pairs_emit_kernel, dim3((unsigned)n_chunks), dim3(kPBlock), 0, st, sid, b, b * (b - 1), offsets,
+                         pair_i, pair_j, capacity, rowpos);
+    }
     MI_LAUNCH_CHECK("pairs_emit_kernel");
   }
   if (n_rows_dev) {
@@ -261,8 +273,11 @@ int mi_create_pairs(const float* embedding_img, const float* embedding_txt, cons
   const int vec_ok = (d_img % 4 == 0) && (d_txt % 4 == 0) && ((((uintptr_t)embedding_img) & 15) == 0) &&
                      ((((uintptr_t)embedding_txt) & 15) == 0) && ((((uintptr_t)out) & 15) == 0);
   const int64_t grid = n_rows < 65536 ? n_rows : 65536;
-  hipLaunchKernelGGL(create_pairs_kernel, dim3((unsigned)grid), dim3(kPBlock), 0, (hipStream_t)stream, embedding_img,
-                     embedding_txt, pair_i, pair_j, n_rows, d_img, d_txt, out, vec_ok);
+  {
+    ProfScope prof_("create_pairs_kernel", (hipStream_t)stream);
+    hipLaunchKernelGGL(create_pairs_kernel, dim3((unsigned)grid), dim3(kPBlock), 0, (hipStream_t)stream, embedding_img,
+                       embedding_txt, pair_i, pair_j, n_rows, d_img, d_txt, out, vec_ok);
+  }
   MI_LAUNCH_CHECK("create_pairs_kernel");
   return MI_OK;
 }
@@ -272,8 +287,11 @@ int mi_create_pairs_bwd(const float* grad_out, const int32_t* rowpos, int64_t b,
   MI_CHECK_ARG(grad_out && grad_img && grad_txt, "mi_create_pairs_bwd: null pointer");
   MI_CHECK_ARG(b >= 1 && d_img >= 1 && d_txt >= 1, "mi_create_pairs_bwd: bad sizes");
   MI_CHECK_ARG(rowpos || b == 1, "mi_create_pairs_bwd: rowpos is required for b > 1");
-  hipLaunchKernelGGL(create_pairs_bwd_kernel, dim3((unsigned)b, 2), dim3(kPBlock), 0, (hipStream_t)stream, grad_out,
-                     rowpos, b, d_img, d_txt, grad_img, grad_txt);
+  {
+    ProfScope prof_("create_pairs_bwd_kernel", (hipStream_t)stream);
+    hipLaunchKernelGGL(create_pairs_bwd_kernel, dim3((unsigned)b, 2), dim3(kPBlock), 0, (hipStream_t)stream, grad_out,
+                       rowpos, b, d_img, d_txt, grad_img, grad_txt);
+  }
   MI_LAUNCH_CHECK("create_pairs_bwd_kernel");
   return MI_OK;
 }

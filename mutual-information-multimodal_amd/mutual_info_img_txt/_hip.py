@@ -29,6 +29,8 @@ _P, _I64, _I, _SZ = c_void_p, c_int64, c_int, c_size_t
 SIGNATURES = {
     "mi_abi_version": (c_int, []),
     "mi_last_error": (c_char_p, []),
+    "mi_profile_begin": (c_int, []),
+    "mi_profile_end": (c_int, [c_char_p, _SZ, ctypes.POINTER(c_float), _I, ctypes.POINTER(c_int)]),
     "mi_bound_workspace_bytes": (_SZ, [_I64]),
     "mi_bound_fwd": (c_int, [_P, _I64, _I64, _I, _P, _P, _P, _SZ, _P]),
     "mi_bound_bwd": (c_int, [_P, _I64, _I64, _P, _P, _P, _P]),
@@ -113,6 +115,38 @@ def workspace(nbytes: int, device) -> torch.Tensor:
 
 def new_stats(device) -> torch.Tensor:
     return torch.empty(STATS_BYTES, dtype=torch.uint8, device=device)
+
+
+class kernel_profile:
+    """Context manager: per-kernel HIP-event timings of every library launch inside the block.
+    ``.records`` is a list of (name, milliseconds) in launch order; ``.by_name()`` aggregates."""
+
+    def __init__(self, capacity: int = 65536):
+        self.capacity = capacity
+        self.records = []
+
+    def __enter__(self):
+        check(load().mi_profile_begin(), "mi_profile_begin")
+        return self
+
+    def __exit__(self, *exc):
+        names = ctypes.create_string_buffer(self.capacity * 48)
+        ms = (c_float * self.capacity)()
+        n = c_int(0)
+        check(load().mi_profile_end(names, len(names), ms, self.capacity, ctypes.byref(n)), "mi_profile_end")
+        parts = names.raw.split(b"\0")
+        self.records = [(parts[k].decode(), float(ms[k])) for k in range(n.value)]
+        return False
+
+    def by_name(self) -> dict:
+        agg = {}
+        for name, t in self.records:
+            a = agg.setdefault(name, {"calls": 0, "ms_total": 0.0})
+            a["calls"] += 1
+            a["ms_total"] += t
+        for a in agg.values():
+            a["ms_avg"] = a["ms_total"] / a["calls"]
+        return agg
 
 
 def stats_dict(stats: torch.Tensor) -> dict:

@@ -1,0 +1,182 @@
+"""Global-batch negatives across the GPUs of one node (one process per GPU, torch.distributed over RCCL/xGMI).
+
+The reference is single-process; "global batch" is defined as the reference loss at B = B_global
+(SURVEY.md 8e).  The B x B score matrix is sharded by row blocks: rank g owns samples [g*B/G, (g+1)*B/G).
+
+forward : all-gather the text embeddings and study ids (the only bulk exchange: B/G x d floats per rank), score the
+          local row block against all columns with the fused kernel, all-gather one 32-byte partial record per rank
+          (max, rescaled sum, positive sum, negative count) and merge the records IN RANK ORDER on every rank, so all
+          ranks hold bit-identical statistics and loss.
+backward: local kernel -> dX of the row block is complete; dY is a partial over this row block for ALL columns ->
+          reduce-scatter; critic-parameter gradients -> all-reduce (sum: the loss is one global scalar).
+
+The local compute is an ``ops`` object.  The product default runs the HIP kernels through the C ABI; the CPU tests
+(gloo, world_size 2) inject an oracle-backed ops object to check the exchange logic without a GPU.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence
+
+import torch
+import torch.distributed as dist
+
+from . import _hip
+
+
+# ----------------------------------------------------------------------------------------------------------
+# local ops through the C ABI (the product path)
+# ----------------------------------------------------------------------------------------------------------
+class HipBilinearOps:
+    """S = (X W) Y^T row block; params = [W]."""
+    n_params = 1
+
+    def forward(self, x, y_all, params, sid_rows, sid_all, row_offset, estimator, precision, need_grad):
+        lib = _hip.load()
+        (w,) = params
+        br, dx = x.shape
+        b, dy = y_all.shape
+        dev = x.device
+        ws = _hip.workspace(lib.mi_bilinear_workspace_bytes(br, b, dx, dy, precision), dev)
+        stats = _hip.new_stats(dev)
+        loss = torch.empty(1, dtype=torch.float32, device=dev)
+        record = torch.empty(_hip.RECORD_FLOATS, dtype=torch.float32, device=dev)
+        _hip.check(lib.mi_bilinear_fwd(x.data_ptr(), y_all.data_ptr(), w.data_ptr(), sid_rows.data_ptr(),
+                                       sid_all.data_ptr(), br, b, row_offset, dx, dy, estimator, precision,
+                                       loss.data_ptr(), stats.data_ptr(), record.data_ptr(), None, ws.data_ptr(),
+                                       ws.numel(), _hip.stream_ptr()), "mi_bilinear_fwd")
+        return record, (x, y_all, w, sid_rows, sid_all, row_offset, precision)
+
+    def merge(self, records, n_pos, estimator):
+        lib = _hip.load()
+        dev = records.device
+        stats = _hip.new_stats(dev)
+        loss = torch.empty(1, dtype=torch.float32, device=dev)
+        _hip.check(lib.mi_merge_partials(records.data_ptr(), records.shape[0], n_pos, estimator, loss.data_ptr(),
+                                         stats.data_ptr(), _hip.stream_ptr()), "mi_merge_partials")
+        return loss, stats
+
+    def backward(self, saved, stats, grad_out):
+        lib = _hip.load()
+        x, y_all, w, sid_rows, sid_all, row_offset, precision = saved
+        br, dx = x.shape
+        b, dy = y_all.shape
+        ws = _hip.workspace(lib.mi_bilinear_workspace_bytes(br, b, dx, dy, precision), x.device)
+        gx, gy, gw = torch.empty_like(x), torch.empty_like(y_all), torch.empty_like(w)
+        _hip.check(lib.mi_bilinear_bwd(x.data_ptr(), y_all.data_ptr(), w.data_ptr(), sid_rows.data_ptr(),
+                                       sid_all.data_ptr(), br, b, row_offset, dx, dy, precision, stats.data_ptr(),
+                                       grad_out.data_ptr(), gx.data_ptr(), gy.data_ptr(), gw.data_ptr(), ws.data_ptr(),
+                                       ws.numel(), _hip.stream_ptr()), "mi_bilinear_bwd")
+        return gx, gy, [gw]
+
+
+class HipConcatMlpOps:
+    """S[i,j] = MLP([x_i ; y_j]) row block; params = [W1, b1, W2, b2, w3 (flat), b3]."""
+    n_params = 6
+
+    def forward(self, x, y_all, params, sid_rows, sid_all, row_offset, estimator, precision, need_grad):
+        lib = _hip.load()
+        br, dx = x.shape
+        b, dy = y_all.shape
+        h1, h2 = params[0].shape[0], params[2].shape[0]
+        dev = x.device
+        ws = _hip.workspace(lib.mi_concat_mlp_workspace_bytes(br, b, dx, dy, h1, h2, precision, int(need_grad)), dev)
+        stats = _hip.new_stats(dev)
+        loss = torch.empty(1, dtype=torch.float32, device=dev)
+        record = torch.empty(_hip.RECORD_FLOATS, dtype=torch.float32, device=dev)
+        scores = torch.empty(br, b, dtype=torch.float32, device=dev)
+        _hip.check(lib.mi_concat_mlp_fwd(x.data_ptr(), y_all.data_ptr(), *[p.data_ptr() for p in params],
+                                         sid_rows.data_ptr(), sid_all.data_ptr(), br, b, row_offset, dx, dy, h1, h2,
+                                         estimator, precision, int(need_grad), loss.data_ptr(), stats.data_ptr(),
+                                         record.data_ptr(), scores.data_ptr(), ws.data_ptr(), ws.numel(),
+                                         _hip.stream_ptr()), "mi_concat_mlp_fwd")
+        return record, (x, y_all, list(params), sid_rows, sid_all, row_offset, precision, scores, ws)
+
+    merge = HipBilinearOps.merge
+
+    def backward(self, saved, stats, grad_out):
+        lib = _hip.load()
+        x, y_all, params, sid_rows, sid_all, row_offset, precision, scores, ws = saved
+        br, dx = x.shape
+        b, dy = y_all.shape
+        h1, h2 = params[0].shape[0], params[2].shape[0]
+        gx, gy = torch.empty_like(x), torch.empty_like(y_all)
+        gp = [torch.empty_like(p) for p in params]
+        _hip.check(lib.mi_concat_mlp_bwd(x.data_ptr(), y_all.data_ptr(), *[p.data_ptr() for p in params],
+                                         sid_rows.data_ptr(), sid_all.data_ptr(), br, b, row_offset, dx, dy, h1, h2,
+                                         precision, stats.data_ptr(), grad_out.data_ptr(), scores.data_ptr(),
+                                         gx.data_ptr(), gy.data_ptr(), *[g.data_ptr() for g in gp], ws.data_ptr(),
+                                         ws.numel(), _hip.stream_ptr()), "mi_concat_mlp_bwd")
+        return gx, gy, gp
+
+
+# ----------------------------------------------------------------------------------------------------------
+# collectives (RCCL on GPUs; gloo in the CPU tests)
+# ----------------------------------------------------------------------------------------------------------
+def _all_gather_rows(t: torch.Tensor, group) -> torch.Tensor:
+    world = dist.get_world_size(group)
+    out = torch.empty((world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+    dist.all_gather_into_tensor(out, t.contiguous(), group=group)
+    return out
+
+
+def _reduce_scatter_rows(t: torch.Tensor, group) -> torch.Tensor:
+    """Sum over ranks of t [G*r, ...], return this rank's block [r, ...]."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    rows = t.shape[0] // world
+    if dist.get_backend(group) == "gloo":  # gloo has no reduce_scatter: all-reduce and slice (CPU tests only)
+        t = t.contiguous()
+        dist.all_reduce(t, group=group)
+        return t[rank * rows:(rank + 1) * rows].clone()
+    out = torch.empty((rows,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+    dist.reduce_scatter_tensor(out, t.contiguous(), group=group)
+    return out
+
+
+class GlobalBatchCriticFn(torch.autograd.Function):
+    """loss over the GLOBAL batch from this rank's row block.  Returns (loss[1], stats)."""
+
+    @staticmethod
+    def forward(ctx, ops, group, estimator: int, precision: int, sid_rows, x, y, *params):
+        world = dist.get_world_size(group)
+        rank = dist.get_rank(group)
+        br = x.shape[0]
+        need_grad = any(t.requires_grad for t in (x, y) + tuple(params))
+        y_all = _all_gather_rows(y, group)
+        sid_all = _all_gather_rows(sid_rows, group)
+        record, saved = ops.forward(x.contiguous(), y_all, [p.contiguous() for p in params], sid_rows.contiguous(),
+                                    sid_all, rank * br, estimator, precision, need_grad)
+        records = _all_gather_rows(record.reshape(1, -1), group)  # [G, 8], rank order
+        loss, stats = ops.merge(records, world * br, estimator)
+        ctx.ops, ctx.group, ctx.saved = ops, group, saved
+        ctx.save_for_backward(stats)
+        ctx.mark_non_differentiable(stats)
+        return loss, stats
+
+    @staticmethod
+    def backward(ctx, grad_loss, _gstats):
+        (stats,) = ctx.saved_tensors
+        go = grad_loss.reshape(-1)[:1].to(torch.float32).contiguous()
+        gx, gy_partial, gparams = ctx.ops.backward(ctx.saved, stats, go)
+        gy = _reduce_scatter_rows(gy_partial, ctx.group)
+        for g in gparams:
+            dist.all_reduce(g, group=ctx.group)
+        return (None, None, None, None, None, gx, gy, *gparams)
+
+
+def global_batch_mi_bound(embedding_img, embedding_txt, study_id_codes, critic_params: Sequence[torch.Tensor],
+                          estimator: str = "infonce", precision: str = "bf16", critic: str = "bilinear", group=None,
+                          ops=None, return_stats: bool = False):
+    """Reference loss at B = world_size * local_batch with this rank's [B/G, d] embeddings.
+    ``study_id_codes``: int64 tensor [B/G] (codes must be consistent across ranks, e.g. the integer study ids).
+    Every rank returns the same loss; ``.backward()`` leaves the gradient of the global loss w.r.t. the local
+    embeddings and the (all-reduced) gradient w.r.t. the critic parameters."""
+    from .mi_critics import _estimator_code, _precision_code
+    if ops is None:
+        ops = {"bilinear": HipBilinearOps, "concat_mlp": HipConcatMlpOps}[critic]()
+    est = _estimator_code(estimator)
+    prec = _precision_code(precision)
+    loss, stats = GlobalBatchCriticFn.apply(ops, group, est, prec, study_id_codes, embedding_img, embedding_txt,
+                                            *critic_params)
+    loss = loss if estimator == "dv" else loss.reshape(())
+    return (loss, stats) if return_stats else loss

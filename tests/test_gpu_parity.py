@@ -337,3 +337,80 @@ def test_concat_bf16_forward_vs_rounded_oracle(dev, b, dx, dy, h1, h2, dup):
     np.testing.assert_allclose(scores.cpu().numpy(), s_r.numpy(), rtol=0, atol=3e-3 * sc)
     np.testing.assert_allclose(scores.cpu().numpy(), s_f.numpy(), rtol=0, atol=3e-2 * sc)
     assert abs(float(loss) - float(orc.bound_from_matrix(s_r, sid, "dv"))) < 3e-3 * sc
+
+
+def _concat_step(dev, x, y, sid, params, hidden, est, precision):
+    from mutual_info_img_txt import mi_critics
+    mlp = _mlp_on(dev, x.shape[1] + y.shape[1], hidden, params)
+    xl, yl = x.to(dev).requires_grad_(True), y.to(dev).requires_grad_(True)
+    loss, scores = mi_critics.fused_mi_bound(xl, yl, sid, mlp, est, precision=precision, return_scores=True)
+    loss.sum().backward()
+    grads = [xl.grad, yl.grad] + [p.grad for p in mlp.parameters()]
+    return loss.detach(), scores, [g.cpu() for g in grads]
+
+
+GRAD_NAMES = ["dx", "dy", "dw1", "db1", "dw2", "db2", "dw3", "db3"]
+
+
+# fp32 MFMA mode, all gradients against the fp64 oracle: |d| <= 3e-4 * max|grad| (+ rtol 2e-3); db3 (true value 0,
+# addends O(1)): |d| <= 1e-5.
+@pytest.mark.parametrize("b,dx,dy,h1,h2,dup", CONCAT_CASES)
+@pytest.mark.parametrize("est", ["dv", "infonce"])
+def test_concat_f32_backward_vs_oracle(dev, b, dx, dy, h1, h2, dup, est):
+    x, y, sid, params = orc.synthetic_case(b, dx, dy, h1=h1, h2=h2, salt=b, dup=dup)
+    loss, scores, grads = _concat_step(dev, x, y, sid, params, (h1, h2), est, "f32")
+    o = orc.concat_matrix_step(x.double(), y.double(), sid, [p.double() for p in params], est)
+    refs = [o["dx"], o["dy"]] + list(o["dparams"])
+    for name, got, ref in zip(GRAD_NAMES, grads, refs):
+        ref = ref.reshape(got.shape)
+        scale = 1.0 if name == "db3" else float(ref.abs().max())
+        np.testing.assert_allclose(got.numpy(), ref.numpy(), rtol=2e-3, atol=(1e-5 if name == "db3" else 3e-4) * scale,
+                                   err_msg=name)
+
+
+@pytest.mark.parametrize("tag", ["b8_d768", "b32_d768", "b16_d768_dup", "b32_d128_dup", "b24_d96x160_dup"])
+def test_concat_f32_backward_golden(dev, golden, tag):
+    """dX, dY and digests of the critic-parameter gradients against the reference's own autograd (fp64 twins)."""
+    g = golden("g3_full_step.npz")
+    b, di, dt_, dup, salt = [int(v) for v in g[f"{tag}/meta"]]
+    x, y, sid, params = orc.synthetic_case(b, di, dt_, salt=salt, dup=bool(dup))
+    loss, scores, grads = _concat_step(dev, x, y, sid, params, (1024, 512), "dv", "f32")
+    k = f"{tag}/dv/f64"
+    np.testing.assert_allclose(loss.cpu().numpy(), g[f"{k}/loss"], rtol=1e-5, atol=3e-5)
+    for name, got in zip(("dx", "dy"), grads[:2]):
+        ref = g[f"{k}/{name}"]
+        np.testing.assert_allclose(got.numpy(), ref, rtol=2e-3, atol=3e-4 * np.abs(ref).max(), err_msg=name)
+    for pn, got in zip(("w1", "b1", "w2", "b2", "w3", "b3"), grads[2:]):
+        a = got.double().numpy()
+        flat = a.reshape(-1)
+        key = f"{k}/d{pn}"
+        scale = 1.0 if pn == "b3" else max(float(np.abs(g[f"{key}/sample"]).max()), float(g[f"{key}/fro"]) / flat.size ** 0.5)
+        tol = (1e-5 if pn == "b3" else 3e-4) * scale
+        np.testing.assert_allclose(flat[g[f"{key}/sample_idx"]], g[f"{key}/sample"], rtol=2e-3, atol=tol, err_msg=pn)
+        np.testing.assert_allclose(np.sqrt((flat ** 2).sum()), g[f"{key}/fro"], rtol=1e-3, atol=tol * flat.size ** 0.5, err_msg=pn)
+        if a.ndim == 2:
+            np.testing.assert_allclose(a.sum(1), g[f"{key}/row_sums"], rtol=2e-3, atol=tol * a.shape[1] ** 0.5 * 4, err_msg=pn)
+            np.testing.assert_allclose(a.sum(0), g[f"{key}/col_sums"], rtol=2e-3, atol=tol * a.shape[0] ** 0.5 * 4, err_msg=pn)
+
+
+# bf16 MFMA mode.  The gradients of this loss cancel heavily (positives -1/B against a softmax that sums to +1,
+# SURVEY.md A.2), so rounding H1 and W2 to bf16 moves them by up to ~25 % of max|grad| relative to fp32 -- for ANY bf16
+# implementation (measured: the fp64 oracle with bf16 rounding at the kernel's rounding points deviates that much).
+# Parity in bf16 mode is therefore defined against that rounded oracle: |d| <= 2e-2 * max|grad|; against the exact
+# oracle only a sanity bound (0.5 * max|grad|) is asserted.  Use precision="f32" where fp32 parity is required.
+@pytest.mark.parametrize("b,dx,dy,h1,h2,dup", CONCAT_CASES[:2] + CONCAT_CASES[3:])
+def test_concat_bf16_backward_vs_rounded_oracle(dev, b, dx, dy, h1, h2, dup):
+    x, y, sid, params = orc.synthetic_case(b, dx, dy, h1=h1, h2=h2, salt=b, dup=dup)
+    loss, scores, grads = _concat_step(dev, x, y, sid, params, (h1, h2), "dv", "bf16")
+    p64 = [p.double() for p in params]
+    o = orc.concat_matrix_step(x.double(), y.double(), sid, p64, "dv")
+    orr = orc.concat_matrix_step(x.double(), y.double(), sid, p64, "dv", round_fn=orc.round_bf16)
+    exact = [o["dx"], o["dy"]] + list(o["dparams"])
+    rounded = [orr["dx"], orr["dy"]] + list(orr["dparams"])
+    for name, got, ref, rref in zip(GRAD_NAMES, grads, exact, rounded):
+        ref, rref = ref.reshape(got.shape), rref.reshape(got.shape)
+        scale = 1.0 if name == "db3" else float(ref.abs().max())
+        err_r = float((got.double() - rref).abs().max()) / scale
+        err_e = float((got.double() - ref).abs().max()) / scale
+        assert err_r < (1e-5 if name == "db3" else 2e-2), (name, err_r)
+        assert err_e < (1e-5 if name == "db3" else 0.5), (name, err_e)
