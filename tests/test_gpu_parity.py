@@ -414,3 +414,50 @@ def test_concat_bf16_backward_vs_rounded_oracle(dev, b, dx, dy, h1, h2, dup):
         err_e = float((got.double() - ref).abs().max()) / scale
         assert err_r < (1e-5 if name == "db3" else 2e-2), (name, err_r)
         assert err_e < (1e-5 if name == "db3" else 0.5), (name, err_e)
+
+
+# ------------------------------------------------------------------------------------------------ row-block sharding
+@pytest.mark.parametrize("critic", ["bilinear", "concat_mlp"])
+@pytest.mark.parametrize("precision", ["f32", "bf16"])
+def test_row_block_sharding_equals_full_batch(dev, critic, precision):
+    """What each rank of an N-GPU run computes (its row block against all columns), emulated on one GPU:
+    merged statistics and summed gradients of G row blocks must equal the single-block result."""
+    from mutual_info_img_txt import _hip
+    from mutual_info_img_txt.distributed import HipBilinearOps, HipConcatMlpOps
+    b, d, G = 192, 64, 3
+    x, y, sid, params = orc.synthetic_case(b, d, d, h1=128, h2=256, salt=5, dup=True)
+    codes = torch.from_numpy(orc.sid_to_int(sid)).to(dev)
+    if critic == "bilinear":
+        ops, plist = HipBilinearOps(), [(orc.hash_uniform((d, d), 7) * 0.5).to(dev)]
+    else:
+        ops, plist = HipConcatMlpOps(), [p.to(dev) for p in params[:4]] + [params[4].reshape(-1).to(dev), params[5].to(dev)]
+    xd, yd = x.to(dev), y.to(dev)
+    prec = _hip.PRECISIONS[precision]
+    go = torch.ones(1, device=dev)
+
+    def run(blocks):
+        recs, saved = [], []
+        br = b // blocks
+        for g in range(blocks):
+            rec, sv = ops.forward(xd[g * br:(g + 1) * br].contiguous(), yd, plist, codes[g * br:(g + 1) * br].contiguous(),
+                                  codes, g * br, _hip.MI_DV, prec, True)
+            recs.append(rec)
+            saved.append(sv)
+        loss, stats = ops.merge(torch.stack(recs), b, _hip.MI_DV)
+        gx, gy, gp = [], torch.zeros_like(yd), [torch.zeros_like(p) for p in plist]
+        for sv in saved:
+            a, c, pp = ops.backward(sv, stats, go)
+            gx.append(a)
+            gy += c
+            for acc, q in zip(gp, pp):
+                acc += q
+        return loss, _hip.stats_dict(stats), torch.cat(gx), gy, gp
+
+    l1, s1, gx1, gy1, gp1 = run(1)
+    lg, sg, gxg, gyg, gpg = run(G)
+    assert s1["n_neg"] == sg["n_neg"] and s1["n_pos"] == sg["n_pos"] == b
+    assert abs(float(l1) - float(lg)) < 2e-6 * max(1.0, abs(float(l1)))
+    tol = 2e-5 if precision == "f32" else 2e-3
+    for a, c in [(gx1, gxg), (gy1, gyg)] + list(zip(gp1, gpg)):
+        scale = max(float(a.abs().max()), 1e-12)
+        assert float((a - c).abs().max()) <= tol * scale + 1e-7
