@@ -92,8 +92,12 @@ def algorithmic_flops(kind, b, d_img, d_txt, h1=1024, h2=512):
 def kernel_flops(name, br, b, d_img, d_txt, h1=1024, h2=512):
     """Algorithmic flops of ONE launch of a named kernel (0 for HBM-bound helper kernels)."""
     if name.startswith("bilinear"):
+        if "|" in name:  # two-problem launch: dT = G Y and dY = G^T T
+            return 4.0 * br * b * d_txt
         if any(t in name for t in ("score+LSE", "bilinear G", "dT = G Y", "dY = G^T T")):
             return 2.0 * br * b * d_txt
+        if "prep" in name:
+            return 0.0
         return 2.0 * br * d_img * d_txt
     if name in ("concat_fwd_kernel", "concat_bwd_duv_kernel", "concat_bwd_dw2_kernel"):
         return 2.0 * br * b * h1 * h2
@@ -214,7 +218,12 @@ def cpu_baseline(kind, args):
     """The oracle (a CPU port of the reference algorithm, pinned to the reference by tests/golden) timed on this box's
     host cores on a bounded sample of the same workload."""
     from oracle import mi_oracle as orc
-    threads = os.cpu_count() or 1
+    # host cores actually available to this process (a 1-GPU box shares a 256-thread host: its CPU share is 16)
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    threads = max(1, min(avail, int(os.environ.get("MI_BENCH_CPU_THREADS", "16"))))
     torch.set_num_threads(threads)
     d = args.dim
     if kind == "bilinear":

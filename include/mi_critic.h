@@ -125,11 +125,14 @@ int mi_bilinear_fwd(const float* x, const float* y, const float* w, const int64_
                     int64_t d_txt, int estimator, int precision, float* loss_out, mi_stats* stats,
                     float* partials_out, float* scores_out, void* workspace, size_t workspace_bytes, void* stream);
 /* stats must hold the GLOBAL lse / n_pos (after the cross-rank merge when sharded). grad_out[0] = dL/dloss.
- * Outputs: grad_x [b_rows, d_img], grad_y [b, d_txt] (partial over this row block), grad_w [d_img, d_txt]. */
+ * Outputs: grad_x [b_rows, d_img], grad_y [b, d_txt] (partial over this row block), grad_w [d_img, d_txt].
+ * workspace_from_forward != 0: `workspace` is the buffer the matching mi_bilinear_fwd call wrote (same inputs); the
+ * backward then reuses the bf16 operand copies and T found there instead of rebuilding them. */
 int mi_bilinear_bwd(const float* x, const float* y, const float* w, const int64_t* sid_rows,
                     const int64_t* sid_cols, int64_t b_rows, int64_t b, int64_t row_offset, int64_t d_img,
                     int64_t d_txt, int precision, const mi_stats* stats, const float* grad_out, float* grad_x,
-                    float* grad_y, float* grad_w, void* workspace, size_t workspace_bytes, void* stream);
+                    float* grad_y, float* grad_w, void* workspace, size_t workspace_bytes,
+                    int workspace_from_forward, void* stream);
 
 /* ---- fused concat-MLP critic (the reference's mi_discriminator) ------------------------------------ */
 /* params in PyTorch [out,in] layout: w1 [h1, d_img+d_txt], b1 [h1], w2 [h2, h1], b2 [h2], w3 [h2], b3 [1]. */

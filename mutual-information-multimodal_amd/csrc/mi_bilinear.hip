@@ -5,38 +5,148 @@
 // The reference has no bilinear critic: scorer parity is pinned by the oracle only; bound, masking and pair
 // semantics are the reference's (mi_critics.py:3-23, main_utils.py:99-108).
 //
-// forward : T = X W                 [b_rows, d_txt]   GEMM
-//           S = T Y^T (tile) -> masked online LSE partial per tile (epilogue), optional S store
-//           merge partials (fixed order) -> stats, loss
-// backward: T = X W (recomputed), G = dloss/dS from recomputed S tiles (epilogue, bf16 or f32, [b_rows, b])
-//           dT = G Y, dY = G^T T, dW = X^T dT, dX = dT W^T       (4 GEMMs)
+// bf16 fast path (all widths and batch sizes multiples of 8): every operand is converted once to bf16 in both
+// orientations so that every GEMM reads K-contiguous rows (mi_gemm_bf16.h):
+//   forward : prep X, Y, W -> T = X W (bf16, both orientations) -> S tiles = T Y^T with masked online-LSE epilogue
+//             -> fixed-order merge -> stats, loss
+//   backward: G = dL/dS from recomputed S tiles (bf16, both orientations, 2 x 33 MB at B = 4096: cache resident)
+//             -> {dT = G Y, dY = G^T T} as ONE two-problem launch (2 x 128 tiles fill the chip) -> dW = X^T dT (split-K
+//             slabs + ordered reduce) -> dX = dT W^T.  The backward reuses the forward's workspace (X, Y, W, T copies).
+// generic path (fp32 parity mode, odd shapes): mi_gemm.h kernels with strided operands, T recomputed in the backward.
 #include "mi_gemm.h"
+#include "mi_gemm_bf16.h"
 
 namespace mi {
 
 struct BilinearPlan {
+  // generic path
   float* t;
   float* dt;
   void* g;
   Partial* partials;
   int64_t n_partials;
+  // bf16 fast path
+  bf16_t *xb, *xtb, *yb, *ytb, *wb, *wtb, *tb, *ttb, *gb, *gtb, *dtb, *dttb;
+  float* dw_slab;
+  int dw_splits;
+  int64_t dw_kchunk;
   size_t bytes;
 };
 
-static BilinearPlan plan_bilinear(Workspace& ws, int64_t br, int64_t b, int64_t d_txt, int precision, bool backward) {
+static bool fast_ok(int64_t br, int64_t b, int64_t dx, int64_t dy, int precision, bool has_w) {
+  return precision == MI_PREC_BF16 && has_w && br % 8 == 0 && b % 8 == 0 && dx % 8 == 0 && dy % 8 == 0;
+}
+
+static BilinearPlan plan_bilinear(Workspace& ws, int64_t br, int64_t b, int64_t dx, int64_t dy, int precision) {
   BilinearPlan p{};
-  p.t = ws.take<float>(br * d_txt);
   p.n_partials = ((b + kTile - 1) / kTile) * ((br + kTile - 1) / kTile);
   p.partials = ws.take<Partial>(p.n_partials);
-  if (backward) {
-    p.dt = ws.take<float>(br * d_txt);
-    if (precision == MI_PREC_BF16) p.g = ws.take<bf16_t>(br * b);
-    else p.g = ws.take<float>(br * b);
-  }
+  // forward buffers of the fast path come first so that forward-only callers can pass a smaller workspace
+  p.xb = ws.take<bf16_t>(br * dx);
+  p.xtb = ws.take<bf16_t>(br * dx);
+  p.yb = ws.take<bf16_t>(b * dy);
+  p.ytb = ws.take<bf16_t>(b * dy);
+  p.wb = ws.take<bf16_t>(dx * dy);
+  p.wtb = ws.take<bf16_t>(dx * dy);
+  p.tb = ws.take<bf16_t>(br * dy);
+  p.ttb = ws.take<bf16_t>(br * dy);
+  p.t = ws.take<float>(br * dy);
+  // backward
+  p.dt = ws.take<float>(br * dy);
+  if (precision == MI_PREC_BF16) p.g = ws.take<bf16_t>(br * b);
+  else p.g = ws.take<float>(br * b);
+  p.gb = (bf16_t*)p.g;
+  p.gtb = ws.take<bf16_t>(br * b);
+  p.dtb = ws.take<bf16_t>(br * dy);
+  p.dttb = ws.take<bf16_t>(br * dy);
+  int64_t tiles = ((dx + kTile - 1) / kTile) * ((dy + kTile - 1) / kTile);
+  int64_t splits = (256 + tiles - 1) / tiles;
+  int64_t kchunk = (br + splits - 1) / splits;
+  kchunk = (kchunk + kG2KT - 1) / kG2KT * kG2KT;
+  splits = (br + kchunk - 1) / kchunk;
+  p.dw_splits = (int)splits;
+  p.dw_kchunk = kchunk;
+  p.dw_slab = ws.take<float>(splits * dx * dy);
   p.bytes = ws.off;
   return p;
 }
 
+static GemmBf16Args one_problem(const bf16_t* a, int64_t lda, const bf16_t* b, int64_t ldb, int64_t m, int64_t n,
+                                int64_t k, int64_t k_chunk = 0) {
+  GemmBf16Args g{};
+  g.p[0] = GemmBf16Problem{a, lda, b, ldb, m, n, k};
+  g.p[1] = g.p[0];
+  g.n_problems = 1;
+  g.k_chunk = k_chunk > 0 ? k_chunk : k;
+  return g;
+}
+
+// ------------------------------------------------------------------------------------------------ fast path
+static int fast_prep_and_t(const float* x, const float* y, const float* w, int64_t br, int64_t b, int64_t dx, int64_t dy,
+                           const BilinearPlan& p, hipStream_t st) {
+  int rc = launch_cvt_transpose(x, br, dx, p.xb, p.xtb, st, "bilinear prep X");
+  if (rc) return rc;
+  rc = launch_cvt_transpose(y, b, dy, p.yb, p.ytb, st, "bilinear prep Y");
+  if (rc) return rc;
+  rc = launch_cvt_transpose(w, dx, dy, p.wb, p.wtb, st, "bilinear prep W");
+  if (rc) return rc;
+  // T[i, c] = sum_a X[i, a] W[a, c]: A = Xb [br][dx], B = W^T [dy][dx]
+  EpiStoreMulti e{};
+  e.out[0] = EpiOut{nullptr, 0, 0, p.tb, dy, p.ttb, br};
+  return launch_gemm_bf16(one_problem(p.xb, dx, p.wtb, dx, br, dy, dx), 1, e, st, "bilinear T = X W");
+}
+
+static int bilinear_fwd_fast(const float* x, const float* y, const float* w, const int64_t* sid_rows,
+                             const int64_t* sid_cols, int64_t br, int64_t b, int64_t row_offset, int64_t dx, int64_t dy,
+                             int estimator, float* loss_out, mi_stats* stats, float* partials_out, float* scores_out,
+                             const BilinearPlan& p, hipStream_t st) {
+  int rc = fast_prep_and_t(x, y, w, br, b, dx, dy, p, st);
+  if (rc) return rc;
+  rc = launch_gemm_bf16(one_problem(p.tb, dy, p.yb, dy, br, b, dy), 1,
+                        EpiScoreLse2{sid_rows, sid_cols, row_offset, scores_out, p.partials}, st, "bilinear score+LSE");
+  if (rc) return rc;
+  return launch_finalize(p.partials, p.n_partials, b, estimator, loss_out, stats, partials_out, st);
+}
+
+static int bilinear_bwd_fast(const int64_t* sid_rows, const int64_t* sid_cols, int64_t br, int64_t b, int64_t row_offset,
+                             int64_t dx, int64_t dy, const mi_stats* stats, const float* grad_out, float* grad_x,
+                             float* grad_y, float* grad_w, const BilinearPlan& p, hipStream_t st) {
+  // G and G^T (bf16) from recomputed score tiles
+  int rc = launch_gemm_bf16(one_problem(p.tb, dy, p.yb, dy, br, b, dy), 1,
+                            EpiGradScore2{sid_rows, sid_cols, row_offset, stats, grad_out, p.gb, p.gtb}, st,
+                            "bilinear G");
+  if (rc) return rc;
+  // problem 0: dT[i, c] = sum_j G[i, j] Y[j, c]   (A = G [br][b], B = Y^T [dy][b])  -> bf16 both orientations
+  // problem 1: dY[j, c] = sum_i G[i, j] T[i, c]   (A = G^T [b][br], B = T^T [dy][br]) -> fp32 grad_y
+  GemmBf16Args two{};
+  two.p[0] = GemmBf16Problem{p.gb, b, p.ytb, b, br, dy, b};
+  two.p[1] = GemmBf16Problem{p.gtb, br, p.ttb, br, b, dy, br};
+  two.n_problems = 2;
+  two.k_chunk = b > br ? b : br;
+  EpiStoreMulti e2{};
+  e2.out[0] = EpiOut{nullptr, 0, 0, p.dtb, dy, p.dttb, br};
+  e2.out[1] = EpiOut{grad_y, dy, 0, nullptr, 0, nullptr, 0};
+  rc = launch_gemm_bf16(two, 1, e2, st, "bilinear dT = G Y | dY = G^T T");
+  if (rc) return rc;
+  // dW[a, c] = sum_i X[i, a] dT[i, c]: A = X^T [dx][br], B = dT^T [dy][br], split over i
+  EpiStoreMulti e3{};
+  e3.out[0] = EpiOut{p.dw_slab, dy, dx * dy, nullptr, 0, nullptr, 0};
+  rc = launch_gemm_bf16(one_problem(p.xtb, br, p.dttb, br, dx, dy, br, p.dw_kchunk), p.dw_splits, e3, st,
+                        "bilinear dW = X^T dT");
+  if (rc) return rc;
+  {
+    ProfScope prof_("slab_reduce_ld_kernel", st);
+    hipLaunchKernelGGL(slab_reduce_ld_kernel, dim3(256), dim3(256), 0, st, (const float*)p.dw_slab, p.dw_splits, dx, dy,
+                       grad_w, dy);
+  }
+  MI_LAUNCH_CHECK("slab_reduce_ld_kernel");
+  // dX[i, a] = sum_c dT[i, c] W[a, c]: A = dT [br][dy], B = W [dx][dy]
+  EpiStoreMulti e4{};
+  e4.out[0] = EpiOut{grad_x, dx, 0, nullptr, 0, nullptr, 0};
+  return launch_gemm_bf16(one_problem(p.dtb, dy, p.wb, dy, br, dx, dy), 1, e4, st, "bilinear dX = dT W^T");
+}
+
+// ------------------------------------------------------------------------------------------------ generic path
 template <typename OpT>
 static int bilinear_fwd_impl(const float* x, const float* y, const float* w, const int64_t* sid_rows,
                              const int64_t* sid_cols, int64_t br, int64_t b, int64_t row_offset, int64_t dx, int64_t dy,
@@ -46,12 +156,13 @@ static int bilinear_fwd_impl(const float* x, const float* y, const float* w, con
   const float* t = x;  // w == nullptr: separable form, the caller passes the projected embeddings (d_img == d_txt)
   if (w) {
     rc = launch_gemm<OpT>(make_operand(x, dx, 1), make_operand(w, 1, dy), br, dy, dx,
-                          EpiStore{p.t, dy, nullptr, 1.0f, 0}, st, "bilinear T = X W");
+                          EpiStore{p.t, dy, nullptr, 1.0f, 0}, st, "bilinear T = X W (generic)");
     if (rc) return rc;
     t = p.t;
   }
   rc = launch_gemm<OpT>(make_operand(t, dy, 1), make_operand(y, dy, 1), br, b, dy,
-                        EpiScoreLse{sid_rows, sid_cols, row_offset, scores_out, p.partials}, st, "bilinear score+LSE");
+                        EpiScoreLse{sid_rows, sid_cols, row_offset, scores_out, p.partials}, st,
+                        "bilinear score+LSE (generic)");
   if (rc) return rc;
   return launch_finalize(p.partials, p.n_partials, b, estimator, loss_out, stats, partials_out, st);
 }
@@ -67,30 +178,26 @@ static int bilinear_bwd_impl(const float* x, const float* y, const float* w, con
   float* dt = grad_x;  // w == nullptr: dT is dX
   if (w) {
     rc = launch_gemm<OpT>(make_operand(x, dx, 1), make_operand(w, 1, dy), br, dy, dx,
-                          EpiStore{p.t, dy, nullptr, 1.0f, 0}, st, "bilinear T = X W (bwd)");
+                          EpiStore{p.t, dy, nullptr, 1.0f, 0}, st, "bilinear T = X W (generic, bwd)");
     if (rc) return rc;
     t = p.t;
     dt = p.dt;
   }
   rc = launch_gemm<OpT>(make_operand(t, dy, 1), make_operand(y, dy, 1), br, b, dy,
-                        EpiGradScore<TG>{sid_rows, sid_cols, row_offset, stats, grad_out, g}, st, "bilinear G");
+                        EpiGradScore<TG>{sid_rows, sid_cols, row_offset, stats, grad_out, g}, st, "bilinear G (generic)");
   if (rc) return rc;
-  // dT[i, c] = sum_j G[i, j] Y[j, c]
   rc = launch_gemm<OpT>(make_operand((const TG*)g, b, 1), make_operand(y, 1, dy), br, dy, b,
-                        EpiStore{dt, dy, nullptr, 1.0f, 0}, st, "bilinear dT = G Y");
+                        EpiStore{dt, dy, nullptr, 1.0f, 0}, st, "bilinear dT = G Y (generic)");
   if (rc) return rc;
-  // dY[j, c] = sum_i G[i, j] T[i, c]
   rc = launch_gemm<OpT>(make_operand((const TG*)g, 1, b), make_operand(t, 1, dy), b, dy, br,
-                        EpiStore{grad_y, dy, nullptr, 1.0f, 0}, st, "bilinear dY = G^T T");
+                        EpiStore{grad_y, dy, nullptr, 1.0f, 0}, st, "bilinear dY = G^T T (generic)");
   if (rc) return rc;
   if (!w) return MI_OK;
-  // dW[a, c] = sum_i X[i, a] dT[i, c]
   rc = launch_gemm<OpT>(make_operand(x, 1, dx), make_operand((const float*)p.dt, 1, dy), dx, dy, br,
-                        EpiStore{grad_w, dy, nullptr, 1.0f, 0}, st, "bilinear dW = X^T dT");
+                        EpiStore{grad_w, dy, nullptr, 1.0f, 0}, st, "bilinear dW = X^T dT (generic)");
   if (rc) return rc;
-  // dX[i, a] = sum_c dT[i, c] W[a, c]
   return launch_gemm<OpT>(make_operand((const float*)p.dt, dy, 1), make_operand(w, dy, 1), br, dx, dy,
-                          EpiStore{grad_x, dx, nullptr, 1.0f, 0}, st, "bilinear dX = dT W^T");
+                          EpiStore{grad_x, dx, nullptr, 1.0f, 0}, st, "bilinear dX = dT W^T (generic)");
 }
 
 static int check_common(const char* fn, int64_t br, int64_t b, int64_t row_offset, int64_t dx, int64_t dy,
@@ -111,9 +218,8 @@ using namespace mi;
 extern "C" {
 
 size_t mi_bilinear_workspace_bytes(int64_t b_rows, int64_t b, int64_t d_img, int64_t d_txt, int precision) {
-  (void)d_img;
   Workspace ws(nullptr, 0);
-  return plan_bilinear(ws, b_rows, b, d_txt, precision, true).bytes + 256;
+  return plan_bilinear(ws, b_rows, b, d_img, d_txt, precision).bytes + 256;
 }
 
 int mi_bilinear_fwd(const float* x, const float* y, const float* w, const int64_t* sid_rows, const int64_t* sid_cols,
@@ -126,12 +232,15 @@ int mi_bilinear_fwd(const float* x, const float* y, const float* w, const int64_
   if (rc) return rc;
   MI_CHECK_ARG(estimator == MI_DV || estimator == MI_INFONCE, "mi_bilinear_fwd: unknown estimator %d", estimator);
   Workspace ws(workspace, workspace_bytes);
-  BilinearPlan p = plan_bilinear(ws, b_rows, b, d_txt, precision, false);
+  BilinearPlan p = plan_bilinear(ws, b_rows, b, d_img, d_txt, precision);
   if (!ws.ok()) {
     set_error("mi_bilinear_fwd: workspace too small (%zu < %zu)", workspace_bytes, ws.off);
     return MI_EWORKSPACE;
   }
   hipStream_t st = (hipStream_t)stream;
+  if (fast_ok(b_rows, b, d_img, d_txt, precision, w != nullptr))
+    return bilinear_fwd_fast(x, y, w, sid_rows, sid_cols, b_rows, b, row_offset, d_img, d_txt, estimator, loss_out,
+                             stats, partials_out, scores_out, p, st);
   if (precision == MI_PREC_BF16)
     return bilinear_fwd_impl<bf16_t>(x, y, w, sid_rows, sid_cols, b_rows, b, row_offset, d_img, d_txt, estimator,
                                      loss_out, stats, partials_out, scores_out, p, st);
@@ -142,7 +251,7 @@ int mi_bilinear_fwd(const float* x, const float* y, const float* w, const int64_
 int mi_bilinear_bwd(const float* x, const float* y, const float* w, const int64_t* sid_rows, const int64_t* sid_cols,
                     int64_t b_rows, int64_t b, int64_t row_offset, int64_t d_img, int64_t d_txt, int precision,
                     const mi_stats* stats, const float* grad_out, float* grad_x, float* grad_y, float* grad_w,
-                    void* workspace, size_t workspace_bytes, void* stream) {
+                    void* workspace, size_t workspace_bytes, int workspace_from_forward, void* stream) {
   MI_CHECK_ARG(x && y && sid_rows && sid_cols && stats && grad_x && grad_y && workspace,
                "mi_bilinear_bwd: null pointer");
   MI_CHECK_ARG((w && grad_w) || (!w && d_img == d_txt),
@@ -150,12 +259,20 @@ int mi_bilinear_bwd(const float* x, const float* y, const float* w, const int64_
   int rc = check_common("mi_bilinear_bwd", b_rows, b, row_offset, d_img, d_txt, precision);
   if (rc) return rc;
   Workspace ws(workspace, workspace_bytes);
-  BilinearPlan p = plan_bilinear(ws, b_rows, b, d_txt, precision, true);
+  BilinearPlan p = plan_bilinear(ws, b_rows, b, d_img, d_txt, precision);
   if (!ws.ok()) {
     set_error("mi_bilinear_bwd: workspace too small (%zu < %zu)", workspace_bytes, ws.off);
     return MI_EWORKSPACE;
   }
   hipStream_t st = (hipStream_t)stream;
+  if (fast_ok(b_rows, b, d_img, d_txt, precision, w != nullptr)) {
+    if (!workspace_from_forward) {  // rebuild the bf16 operand copies and T
+      rc = fast_prep_and_t(x, y, w, b_rows, b, d_img, d_txt, p, st);
+      if (rc) return rc;
+    }
+    return bilinear_bwd_fast(sid_rows, sid_cols, b_rows, b, row_offset, d_img, d_txt, stats, grad_out, grad_x, grad_y,
+                             grad_w, p, st);
+  }
   if (precision == MI_PREC_BF16)
     return bilinear_bwd_impl<bf16_t, bf16_t>(x, y, w, sid_rows, sid_cols, b_rows, b, row_offset, d_img, d_txt, stats,
                                              grad_out, grad_x, grad_y, grad_w, p, st);

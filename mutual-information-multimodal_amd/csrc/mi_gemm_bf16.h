@@ -1,0 +1,308 @@
+// bf16 MFMA GEMM for K-contiguous bf16 operands (the fast path of the bilinear critic):
+//   C[m, n] = sum_k A[m][k] * B[n][k]        A: [M][lda], B: [N][ldb], bf16, 16-byte aligned rows, K % 8 == 0
+// Up to two independent problems per launch (blockIdx.z selects; fills the chip when one problem has only 128 tiles)
+// and split-K by blockIdx.z for a single problem (partial sums go to slabs, reduced in a fixed order afterwards).
+//
+// 128 x 128 x 64 tiles, 256 threads = 4 waves (2 x 2), each 64 x 64 = 2 x 2 v_mfma_f32_32x32x16_bf16 tiles.
+// Global -> registers -> LDS staging, double-buffered LDS (one barrier per K tile): the next tile's 16-byte loads are
+// issued before the current tile's 16 MFMAs and written to the other buffer after them (guide T14).  LDS rows are
+// padded to 144 bytes, which makes every ds_read_b128 fragment read conflict-free.  72 KB of LDS -> 2 workgroups / CU.
+#pragma once
+#include "mi_common.h"
+#include "mi_gemm.h"
+
+namespace mi {
+
+constexpr int kG2KT = 64;   // k per tile
+constexpr int kG2LD = 72;   // LDS row pitch in bf16 elements
+
+struct GemmBf16Problem {
+  const bf16_t* a;
+  int64_t lda;
+  const bf16_t* b;
+  int64_t ldb;
+  int64_t m, n, k;
+};
+
+struct GemmBf16Args {
+  GemmBf16Problem p[2];
+  int n_problems;   // 1 or 2
+  int64_t k_chunk;  // split-K chunk (multiple of 64) when n_problems == 1 and gridDim.z > 1; else >= k
+};
+
+// Generic multi-output store epilogue (one set of outputs per problem): out = alpha * acc
+struct EpiOut {
+  float* f32;           // [M][ld_f32] or null; split-K: slab z at f32 + z * slab_stride
+  int64_t ld_f32;
+  int64_t slab_stride;
+  bf16_t* bf;           // [M][ld_bf] or null
+  int64_t ld_bf;
+  bf16_t* bf_t;         // transposed [N][ld_bf_t] or null
+  int64_t ld_bf_t;
+};
+
+template <class F>
+__device__ __forceinline__ void foreach_acc4(f32x16 (&acc)[2][2], int64_t m_base, int64_t n_base, F&& f) {
+  // groups of 4 consecutive rows: f(row0, col, v0..v3)
+  const int lane = threadIdx.x & 63;
+  const int col_l = lane & 31, half = lane >> 5;
+#pragma unroll
+  for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int64_t row0 = m_base + tm * 32 + 8 * g + 4 * half;
+        const int64_t col = n_base + tn * 32 + col_l;
+        f(row0, col, acc[tm][tn][4 * g], acc[tm][tn][4 * g + 1], acc[tm][tn][4 * g + 2], acc[tm][tn][4 * g + 3]);
+      }
+}
+
+__device__ __forceinline__ void store4_transposed(bf16_t* dst_t, int64_t ld_t, int64_t row0, int64_t col, int64_t M,
+                                                  float v0, float v1, float v2, float v3) {
+  bf16_t* p = dst_t + col * ld_t + row0;
+  if (row0 + 3 < M && ((ld_t & 3) == 0)) {
+    bf16x4 v = {(bf16_t)v0, (bf16_t)v1, (bf16_t)v2, (bf16_t)v3};
+    *reinterpret_cast<bf16x4*>(p) = v;
+  } else {
+    const float vv[4] = {v0, v1, v2, v3};
+    for (int q = 0; q < 4; ++q)
+      if (row0 + q < M) p[q] = (bf16_t)vv[q];
+  }
+}
+
+struct EpiStoreMulti {
+  EpiOut out[2];
+  __device__ __forceinline__ void operator()(f32x16 (&acc)[2][2], int64_t mb, int64_t nb, int64_t M, int64_t N, int prob,
+                                             int zsplit) const {
+    const EpiOut& o = out[prob];
+    if (o.f32 || o.bf) {
+      float* f = o.f32 ? o.f32 + (int64_t)zsplit * o.slab_stride : nullptr;
+      foreach_acc(acc, mb, nb, [&](int64_t row, int64_t col, float v) {
+        if (row < M && col < N) {
+          if (f) f[row * o.ld_f32 + col] = v;
+          if (o.bf) o.bf[row * o.ld_bf + col] = (bf16_t)v;
+        }
+      });
+    }
+    if (o.bf_t) {
+      foreach_acc4(acc, mb, nb, [&](int64_t row0, int64_t col, float v0, float v1, float v2, float v3) {
+        if (col < N) store4_transposed(o.bf_t, o.ld_bf_t, row0, col, M, v0, v1, v2, v3);
+      });
+    }
+  }
+};
+
+// masked log-sum-exp partial per workgroup (bilinear forward), optional fp32 score store
+struct EpiScoreLse2 {
+  const int64_t* sid_rows;
+  const int64_t* sid_cols;
+  int64_t row_offset;
+  float* scores;
+  Partial* partials;
+  __device__ __forceinline__ void operator()(f32x16 (&acc)[2][2], int64_t mb, int64_t nb, int64_t M, int64_t N, int,
+                                             int) const {
+    EpiScoreLse e{sid_rows, sid_cols, row_offset, scores, partials};
+    e(acc, mb, nb, M, N);
+  }
+};
+
+// G = grad_out * dL/dS as bf16, row-major [M][N] and transposed [N][M]
+struct EpiGradScore2 {
+  const int64_t* sid_rows;
+  const int64_t* sid_cols;
+  int64_t row_offset;
+  const mi_stats* stats;
+  const float* grad_out;
+  bf16_t* g;
+  bf16_t* gt;
+  __device__ __forceinline__ void operator()(f32x16 (&acc)[2][2], int64_t mb, int64_t nb, int64_t M, int64_t N, int,
+                                             int) const {
+    const float go = grad_out ? grad_out[0] : 1.0f;
+    const float lse = stats->lse;
+    const float gpos = -go / (float)stats->n_pos;
+    // overwrite the accumulators with G, then store both orientations
+    const int lane = threadIdx.x & 63;
+    const int col_l = lane & 31, half = lane >> 5;
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+      for (int tn = 0; tn < 2; ++tn) {
+        const int64_t col = nb + tn * 32 + col_l;
+        const int64_t sc = col < N ? sid_cols[col] : 0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int64_t row = mb + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+          float gv = 0.0f;
+          if (row < M && col < N) {
+            const int kind = pair_kind(row_offset + row, col, sid_rows[row], sc);
+            if (kind == 1) gv = gpos;
+            else if (kind == 2) gv = go * expf(acc[tm][tn][r] - lse);
+            g[row * N + col] = (bf16_t)gv;
+          }
+          acc[tm][tn][r] = gv;
+        }
+      }
+    foreach_acc4(acc, mb, nb, [&](int64_t row0, int64_t col, float v0, float v1, float v2, float v3) {
+      if (col < N) store4_transposed(gt, M, row0, col, M, v0, v1, v2, v3);
+    });
+  }
+};
+
+template <class Epi>
+__global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmBf16Args args, Epi epi) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  bf16_t* As = reinterpret_cast<bf16_t*>(smem_raw);      // [2][128][72]
+  bf16_t* Bs = As + 2 * kTile * kG2LD;                    // [2][128][72]
+
+  const int prob = args.n_problems == 2 ? (int)blockIdx.z : 0;
+  const int zsplit = args.n_problems == 2 ? 0 : (int)blockIdx.z;
+  const GemmBf16Problem& P = args.p[prob];
+  const int64_t m0 = (int64_t)blockIdx.y * kTile, n0 = (int64_t)blockIdx.x * kTile;
+  if (m0 >= P.m || n0 >= P.n) return;  // the grid covers the larger of two problems
+  const int64_t kbeg = (int64_t)zsplit * args.k_chunk;
+  int64_t kend = kbeg + args.k_chunk;
+  if (kend > P.k) kend = P.k;
+
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int r32 = lane & 31, half = lane >> 5;
+  const int srow = tid >> 3, skv = tid & 7;  // staging: rows srow + 32 q, 16-byte vector skv of the row
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+
+  u32x4 ra[4], rb[4];
+  auto load_tile = [&](int64_t k0) {
+    const int64_t k = k0 + skv * 8;
+    const bool kin = k + 7 < kend;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int64_t am = m0 + srow + 32 * q, bn = n0 + srow + 32 * q;
+      const u32x4 z = {0u, 0u, 0u, 0u};
+      ra[q] = (kin && am < P.m) ? *reinterpret_cast<const u32x4*>(P.a + am * P.lda + k) : z;
+      rb[q] = (kin && bn < P.n) ? *reinterpret_cast<const u32x4*>(P.b + bn * P.ldb + k) : z;
+    }
+  };
+  auto store_tile = [&](int buf) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      *reinterpret_cast<u32x4*>(&As[(buf * kTile + srow + 32 * q) * kG2LD + skv * 8]) = ra[q];
+      *reinterpret_cast<u32x4*>(&Bs[(buf * kTile + srow + 32 * q) * kG2LD + skv * 8]) = rb[q];
+    }
+  };
+
+  const int64_t nt = (kend - kbeg + kG2KT - 1) / kG2KT;
+  if (nt > 0) {
+    load_tile(kbeg);
+    store_tile(0);
+  }
+  __syncthreads();
+  for (int64_t t = 0; t < nt; ++t) {
+    const int buf = (int)(t & 1);
+    const bool more = t + 1 < nt;
+    if (more) load_tile(kbeg + (t + 1) * kG2KT);
+    const bf16_t* at = As + buf * kTile * kG2LD;
+    const bf16_t* bt = Bs + buf * kTile * kG2LD;
+#pragma unroll
+    for (int kk = 0; kk < kG2KT / 16; ++kk) {
+      bf16x8 af[2], bfr[2];
+#pragma unroll
+      for (int tm = 0; tm < 2; ++tm)
+        af[tm] = *reinterpret_cast<const bf16x8*>(&at[(wm * 64 + tm * 32 + r32) * kG2LD + kk * 16 + 8 * half]);
+#pragma unroll
+      for (int tn = 0; tn < 2; ++tn)
+        bfr[tn] = *reinterpret_cast<const bf16x8*>(&bt[(wn * 64 + tn * 32 + r32) * kG2LD + kk * 16 + 8 * half]);
+#pragma unroll
+      for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn)
+          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[tm], bfr[tn], acc[tm][tn], 0, 0, 0);
+    }
+    if (more) store_tile(buf ^ 1);
+    __syncthreads();
+  }
+  epi(acc, m0 + wm * 64, n0 + wn * 64, P.m, P.n, prob, zsplit);
+}
+
+constexpr size_t kG2Smem = 2 * 2 * kTile * kG2LD * sizeof(bf16_t);  // 73,728 bytes
+
+template <class Epi>
+static inline int launch_gemm_bf16(const GemmBf16Args& args, int n_splits, const Epi& epi, hipStream_t st,
+                                   const char* what) {
+  int64_t mm = args.p[0].m, nn = args.p[0].n;
+  if (args.n_problems == 2) {
+    if (args.p[1].m > mm) mm = args.p[1].m;
+    if (args.p[1].n > nn) nn = args.p[1].n;
+  }
+  if (mm <= 0 || nn <= 0) return MI_OK;
+  static bool attr_set = false;  // per Epi instantiation
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_kernel<Epi>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)kG2Smem);
+    if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(gemm_bf16_kernel)");
+    attr_set = true;
+  }
+  dim3 grid((unsigned)((nn + kTile - 1) / kTile), (unsigned)((mm + kTile - 1) / kTile),
+            (unsigned)(args.n_problems == 2 ? 2 : n_splits));
+  {
+    ProfScope prof_(what, st);
+    hipLaunchKernelGGL((gemm_bf16_kernel<Epi>), grid, dim3(256), kG2Smem, st, args, epi);
+  }
+  MI_LAUNCH_CHECK(what);
+  return MI_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ prep kernels
+// in [R][C] fp32 -> out_rm [R][C] bf16 (optional) and out_t [C][R] bf16 (optional); 32 x 32 tiles through LDS
+__global__ __launch_bounds__(256) void cvt_transpose_kernel(const float* __restrict__ in, int64_t R, int64_t C,
+                                                            bf16_t* __restrict__ out_rm, bf16_t* __restrict__ out_t) {
+  __shared__ float tile[32][33];
+  const int64_t r0 = (int64_t)blockIdx.y * 32, c0 = (int64_t)blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 8 row groups
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int64_t r = r0 + ty + 8 * q, c = c0 + tx;
+    const float v = (r < R && c < C) ? in[r * C + c] : 0.0f;
+    tile[ty + 8 * q][tx] = v;
+    if (out_rm && r < R && c < C) out_rm[r * C + c] = (bf16_t)v;
+  }
+  if (!out_t) return;
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int64_t c = c0 + ty + 8 * q, r = r0 + tx;
+    if (c < C && r < R) out_t[c * R + r] = (bf16_t)tile[tx][ty + 8 * q];
+  }
+}
+
+static inline int launch_cvt_transpose(const float* in, int64_t R, int64_t C, bf16_t* out_rm, bf16_t* out_t,
+                                       hipStream_t st, const char* what) {
+  dim3 grid((unsigned)((C + 31) / 32), (unsigned)((R + 31) / 32));
+  {
+    ProfScope prof_(what, st);
+    hipLaunchKernelGGL(cvt_transpose_kernel, grid, dim3(256), 0, st, in, R, C, out_rm, out_t);
+  }
+  MI_LAUNCH_CHECK(what);
+  return MI_OK;
+}
+
+// out[r][c] (ld = ldo) = sum_s slab[s][r][c]   (fixed order)
+__global__ void slab_reduce_ld_kernel(const float* __restrict__ slab, int n_slab, int64_t rows, int64_t cols,
+                                      float* __restrict__ out, int64_t ldo) {
+  const int64_t total = rows * cols;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+    float a = slab[e];
+    for (int s = 1; s < n_slab; ++s) a += slab[(int64_t)s * total + e];
+    out[(e / cols) * ldo + (e % cols)] = a;
+  }
+}
+
+}  // namespace mi

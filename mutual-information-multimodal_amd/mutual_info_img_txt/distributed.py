@@ -44,7 +44,7 @@ class HipBilinearOps:
                                        sid_all.data_ptr(), br, b, row_offset, dx, dy, estimator, precision,
                                        loss.data_ptr(), stats.data_ptr(), record.data_ptr(), None, ws.data_ptr(),
                                        ws.numel(), _hip.stream_ptr()), "mi_bilinear_fwd")
-        return record, (x, y_all, w, sid_rows, sid_all, row_offset, precision)
+        return record, (x, y_all, w, sid_rows, sid_all, row_offset, precision, ws)
 
     def merge(self, records, n_pos, estimator):
         lib = _hip.load()
@@ -57,15 +57,14 @@ class HipBilinearOps:
 
     def backward(self, saved, stats, grad_out):
         lib = _hip.load()
-        x, y_all, w, sid_rows, sid_all, row_offset, precision = saved
+        x, y_all, w, sid_rows, sid_all, row_offset, precision, ws = saved
         br, dx = x.shape
         b, dy = y_all.shape
-        ws = _hip.workspace(lib.mi_bilinear_workspace_bytes(br, b, dx, dy, precision), x.device)
         gx, gy, gw = torch.empty_like(x), torch.empty_like(y_all), torch.empty_like(w)
         _hip.check(lib.mi_bilinear_bwd(x.data_ptr(), y_all.data_ptr(), w.data_ptr(), sid_rows.data_ptr(),
                                        sid_all.data_ptr(), br, b, row_offset, dx, dy, precision, stats.data_ptr(),
                                        grad_out.data_ptr(), gx.data_ptr(), gy.data_ptr(), gw.data_ptr(), ws.data_ptr(),
-                                       ws.numel(), _hip.stream_ptr()), "mi_bilinear_bwd")
+                                       ws.numel(), 1, _hip.stream_ptr()), "mi_bilinear_bwd")
         return gx, gy, [gw]
 
 

@@ -178,7 +178,7 @@ class BilinearCriticFn(torch.autograd.Function):
                                        dx, dy, estimator, precision, loss.data_ptr(), stats.data_ptr(),
                                        record.data_ptr(), _hip.ptr(scores), ws.data_ptr(), ws.numel(),
                                        _hip.stream_ptr()), "mi_bilinear_fwd")
-        ctx.save_for_backward(x, y, sid, stats, *([] if w is None else [w]))
+        ctx.save_for_backward(x, y, sid, stats, ws, *([] if w is None else [w]))
         ctx.precision = precision
         ctx.mark_non_differentiable(stats)
         if want_scores:
@@ -189,18 +189,16 @@ class BilinearCriticFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_loss, _gs, _gsc):
         lib = _hip.load()
-        x, y, sid, stats, *rest = ctx.saved_tensors
+        x, y, sid, stats, ws, *rest = ctx.saved_tensors
         w = rest[0] if rest else None
         b, dx = x.shape
         dy = y.shape[1]
-        dev = x.device
         go = _grad_scalar(grad_loss)
-        ws = _hip.workspace(lib.mi_bilinear_workspace_bytes(b, b, dx, dy, ctx.precision), dev)
         gx, gy = torch.empty_like(x), torch.empty_like(y)
         gw = None if w is None else torch.empty_like(w)
         _hip.check(lib.mi_bilinear_bwd(x.data_ptr(), y.data_ptr(), _hip.ptr(w), sid.data_ptr(), sid.data_ptr(), b, b, 0,
                                        dx, dy, ctx.precision, stats.data_ptr(), go.data_ptr(), gx.data_ptr(),
-                                       gy.data_ptr(), _hip.ptr(gw), ws.data_ptr(), ws.numel(), _hip.stream_ptr()),
+                                       gy.data_ptr(), _hip.ptr(gw), ws.data_ptr(), ws.numel(), 1, _hip.stream_ptr()),
                    "mi_bilinear_bwd")
         return gx, gy, gw, None, None, None, None
 
