@@ -102,8 +102,51 @@ struct EpiScoreLse2 {
   Partial* partials;
   __device__ __forceinline__ void operator()(f32x16 (&acc)[2][2], int64_t mb, int64_t nb, int64_t M, int64_t N, int,
                                              int) const {
-    EpiScoreLse e{sid_rows, sid_cols, row_offset, scores, partials};
-    e(acc, mb, nb, M, N);
+    // Two passes over the 64 accumulators of this lane: the maximum of its negatives first, then one hardware
+    // exponential (v_exp_f32) per negative -- no data-dependent rescale branch (bf16 mode: the scores themselves
+    // carry ~1e-2 relative error, the native exponential's 1e-6 is irrelevant here).
+    __shared__ Partial scratch[4];
+    const int lane = threadIdx.x & 63;
+    const int col_l = lane & 31, half = lane >> 5;
+    float mx = MI_NEG_INF, pos = 0.0f;
+    unsigned cnt = 0;
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+      for (int tn = 0; tn < 2; ++tn) {
+        const int64_t col = nb + tn * 32 + col_l;
+        const int64_t sc = col < N ? sid_cols[col] : 0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int64_t row = mb + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+          float v = acc[tm][tn][r];
+          int kind = 0;
+          if (row < M && col < N) {
+            if (scores) scores[row * N + col] = v;
+            kind = pair_kind(row_offset + row, col, sid_rows[row], sc);
+          }
+          if (kind == 1) pos += v;
+          if (kind == 2) {
+            mx = fmaxf(mx, v);
+            cnt += 1;
+          } else {
+            v = MI_NEG_INF;  // contributes exp(-inf) = 0 below
+          }
+          acc[tm][tn][r] = v;
+        }
+      }
+    float s = 0.0f;
+    if (cnt > 0) {
+#pragma unroll
+      for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) s += __expf(acc[tm][tn][r] - mx);
+    }
+    Partial p{mx, s, pos, cnt};
+    p = block_reduce_partial<4>(p, scratch);
+    if (threadIdx.x == 0) partials[(int64_t)blockIdx.y * gridDim.x + blockIdx.x] = p;
   }
 };
 
@@ -137,7 +180,7 @@ struct EpiGradScore2 {
           if (row < M && col < N) {
             const int kind = pair_kind(row_offset + row, col, sid_rows[row], sc);
             if (kind == 1) gv = gpos;
-            else if (kind == 2) gv = go * expf(acc[tm][tn][r] - lse);
+            else if (kind == 2) gv = go * __expf(acc[tm][tn][r] - lse);  // bf16 output: native exp is ample
             g[row * N + col] = (bf16_t)gv;
           }
           acc[tm][tn][r] = gv;
@@ -155,8 +198,8 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmBf16Args args, Ep
   bf16_t* As = reinterpret_cast<bf16_t*>(smem_raw);      // [2][128][72]
   bf16_t* Bs = As + 2 * kTile * kG2LD;                    // [2][128][72]
 
-  const int prob = args.n_problems == 2 ? (int)blockIdx.z : 0;
-  const int zsplit = args.n_problems == 2 ? 0 : (int)blockIdx.z;
+  const int prob = (int)blockIdx.z % args.n_problems;
+  const int zsplit = (int)blockIdx.z / args.n_problems;
   const GemmBf16Problem& P = args.p[prob];
   const int64_t m0 = (int64_t)blockIdx.y * kTile, n0 = (int64_t)blockIdx.x * kTile;
   if (m0 >= P.m || n0 >= P.n) return;  // the grid covers the larger of two problems
@@ -231,6 +274,106 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmBf16Args args, Ep
   epi(acc, m0 + wm * 64, n0 + wn * 64, P.m, P.n, prob, zsplit);
 }
 
+
+// ------------------------------------------------------------------------------------------------ LDS-DMA variant
+// Same tiling, but the tiles go HBM/L2 -> LDS directly (global_load_lds_dwordx4: no staging registers, no ds_write
+// pass).  The DMA writes a wave's 64 x 16 bytes linearly, so the LDS image is unpadded [128 rows][128 bytes] and bank
+// conflicts are removed by an XOR swizzle applied on the SOURCE address and again on the fragment read (guide rule 21):
+//   chunk c (16 bytes = 8 k) of row r lives at LDS chunk position c ^ ((r >> 1) & 7).
+// Requires K (and the split-K chunk) to be multiples of 64; rows beyond M / N are clamped (they only feed outputs that
+// the epilogue discards).  64 KB of LDS -> 2 workgroups per CU.
+template <class Epi>
+__global__ __launch_bounds__(256, 2) void gemm_bf16_glds_kernel(GemmBf16Args args, Epi epi) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  // [buf][A | B][128 rows][128 bytes]
+  const int prob = (int)blockIdx.z % args.n_problems;
+  const int zsplit = (int)blockIdx.z / args.n_problems;
+  const GemmBf16Problem& P = args.p[prob];
+  const int64_t m0 = (int64_t)blockIdx.y * kTile, n0 = (int64_t)blockIdx.x * kTile;
+  if (m0 >= P.m || n0 >= P.n) return;
+  const int64_t kbeg = (int64_t)zsplit * args.k_chunk;
+  int64_t kend = kbeg + args.k_chunk;
+  if (kend > P.k) kend = P.k;
+
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int r32 = lane & 31, half = lane >> 5;
+
+  // staging: wave w, instruction i (0..3): rows 32 w + 8 i + (lane >> 3), LDS chunk position lane & 7
+  const char* asrc[4];
+  const char* bsrc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = 32 * wave + 8 * i + (lane >> 3);
+    const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+    int64_t am = m0 + row, bn = n0 + row;
+    if (am >= P.m) am = P.m - 1;
+    if (bn >= P.n) bn = P.n - 1;
+    asrc[i] = reinterpret_cast<const char*>(P.a + am * P.lda + kbeg) + chunk * 16;
+    bsrc[i] = reinterpret_cast<const char*>(P.b + bn * P.ldb + kbeg) + chunk * 16;
+  }
+  auto issue_tile = [&](int64_t t, int buf) {
+    char* abase = smem_raw + buf * 32768 + (32 * wave) * 128;
+    char* bbase = abase + 16384;
+    const int64_t koff = t * (kG2KT * 2);  // bytes
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(asrc[i] + koff),
+                                       (__attribute__((address_space(3))) void*)(abase + i * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bsrc[i] + koff),
+                                       (__attribute__((address_space(3))) void*)(bbase + i * 1024), 16, 0, 0);
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+
+  // fragment read offsets (bytes within a 16 KB operand tile), per kk the chunk index is 2 kk + half
+  int aoff[2], boff[2], aswz[2], bswz[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int ar = wm * 64 + t * 32 + r32, br_ = wn * 64 + t * 32 + r32;
+    aoff[t] = ar * 128;
+    boff[t] = br_ * 128;
+    aswz[t] = (ar >> 1) & 7;
+    bswz[t] = (br_ >> 1) & 7;
+  }
+
+  const int64_t nt = (kend - kbeg) / kG2KT;
+  if (nt > 0) issue_tile(0, 0);
+  __syncthreads();
+  for (int64_t t = 0; t < nt; ++t) {
+    const int buf = (int)(t & 1);
+    if (t + 1 < nt) issue_tile(t + 1, buf ^ 1);
+    const char* at = smem_raw + buf * 32768;
+    const char* bt = at + 16384;
+#pragma unroll
+    for (int kk = 0; kk < kG2KT / 16; ++kk) {
+      bf16x8 af[2], bfr[2];
+#pragma unroll
+      for (int tm = 0; tm < 2; ++tm)
+        af[tm] = *reinterpret_cast<const bf16x8*>(at + aoff[tm] + 16 * ((2 * kk + half) ^ aswz[tm]));
+#pragma unroll
+      for (int tn = 0; tn < 2; ++tn)
+        bfr[tn] = *reinterpret_cast<const bf16x8*>(bt + boff[tn] + 16 * ((2 * kk + half) ^ bswz[tn]));
+#pragma unroll
+      for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn)
+          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[tm], bfr[tn], acc[tm][tn], 0, 0, 0);
+    }
+    __syncthreads();  // hipcc waits vmcnt(0) before the barrier: tile t+1 has landed, buffer `buf` is free
+  }
+  epi(acc, m0 + wm * 64, n0 + wn * 64, P.m, P.n, prob, zsplit);
+}
+
+constexpr size_t kG2SmemGlds = 2 * 2 * 16384;  // 65,536 bytes
 constexpr size_t kG2Smem = 2 * 2 * kTile * kG2LD * sizeof(bf16_t);  // 73,728 bytes
 
 template <class Epi>
@@ -247,13 +390,19 @@ static inline int launch_gemm_bf16(const GemmBf16Args& args, int n_splits, const
     hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_kernel<Epi>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)kG2Smem);
     if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(gemm_bf16_kernel)");
+    e = hipFuncSetAttribute((const void*)gemm_bf16_glds_kernel<Epi>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)kG2SmemGlds);
+    if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(gemm_bf16_glds_kernel)");
     attr_set = true;
   }
+  bool dma_ok = args.k_chunk % kG2KT == 0 || n_splits == 1;
+  for (int q = 0; q < args.n_problems; ++q) dma_ok = dma_ok && args.p[q].k % kG2KT == 0 && args.p[q].k > 0;
   dim3 grid((unsigned)((nn + kTile - 1) / kTile), (unsigned)((mm + kTile - 1) / kTile),
-            (unsigned)(args.n_problems == 2 ? 2 : n_splits));
+            (unsigned)(args.n_problems * n_splits));
   {
     ProfScope prof_(what, st);
-    hipLaunchKernelGGL((gemm_bf16_kernel<Epi>), grid, dim3(256), kG2Smem, st, args, epi);
+    if (dma_ok) hipLaunchKernelGGL((gemm_bf16_glds_kernel<Epi>), grid, dim3(256), kG2SmemGlds, st, args, epi);
+    else hipLaunchKernelGGL((gemm_bf16_kernel<Epi>), grid, dim3(256), kG2Smem, st, args, epi);
   }
   MI_LAUNCH_CHECK(what);
   return MI_OK;
