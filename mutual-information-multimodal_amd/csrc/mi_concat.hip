@@ -7,6 +7,7 @@
 #include "mi_concat_bwd.h"
 #include "mi_concat_fwd.h"
 #include "mi_gemm.h"
+#include "mi_gemm_bf16.h"
 
 namespace mi {
 
@@ -32,6 +33,10 @@ struct ConcatPlan {
   float* d_slab;
   float* m_slab;
   float* g_sum;
+  float* w1_slab;
+  float* col_part;
+  int n_w1split;
+  int64_t w1_kchunk_x, w1_kchunk_y;
   int n_jsplit, cols_per_split, n_iblk;
   int n_dsplit, rows_per_dsplit;
   int n_msplit, rows_per_msplit;
@@ -39,7 +44,7 @@ struct ConcatPlan {
 };
 
 static ConcatPlan plan_concat(Workspace& ws, int64_t br, int64_t b, int64_t h1, int64_t h2, int precision,
-                              int need_grad) {
+                              int need_grad, int64_t dmax) {
   ConcatPlan p{};
   p.u = ws.take<float>(br * h1);
   p.v = ws.take<float>(b * h1);
@@ -62,7 +67,7 @@ static ConcatPlan plan_concat(Workspace& ws, int64_t br, int64_t b, int64_t h1, 
     if (rps < 16) rps = 16;
     p.rows_per_dsplit = (int)rps;
     p.n_dsplit = (int)((br + rps - 1) / rps);
-    int64_t rpm = (br + 255) / 256;
+    int64_t rpm = (br + 1023) / 1024;
     p.rows_per_msplit = (int)rpm;
     p.n_msplit = (int)((br + rpm - 1) / rpm);
     if (precision == MI_PREC_BF16) p.w2wp = ws.take<bf16_t>(h1 * h2);
@@ -74,6 +79,15 @@ static ConcatPlan plan_concat(Workspace& ws, int64_t br, int64_t b, int64_t h1, 
     p.d_slab = ws.take<float>((int64_t)p.n_dsplit * h2 * h1);
     p.m_slab = ws.take<float>((int64_t)p.n_msplit * h2);
     p.g_sum = ws.take<float>(p.n_msplit);
+    // dW1 = [dU^T X | dV^T Y]: K = batch; few output tiles -> split-K slabs (16 splits of >= 64 samples)
+    int64_t sp = (b + 63) / 64;
+    if (sp > 16) sp = 16;
+    if (sp < 1) sp = 1;
+    p.n_w1split = (int)sp;
+    p.w1_kchunk_x = ((br + sp - 1) / sp + 15) / 16 * 16;
+    p.w1_kchunk_y = ((b + sp - 1) / sp + 15) / 16 * 16;
+    p.w1_slab = ws.take<float>(sp * h1 * (dmax > 0 ? dmax : 1));
+    p.col_part = ws.take<float>(64 * h1);
   }
   p.bytes = ws.off;
   return p;
@@ -200,16 +214,39 @@ static int concat_bwd_impl(const float* x, const float* y, const float* w1, cons
   rc = launch_gemm<float>(make_operand((const float*)p.dv, h1, 1), make_operand(w1 + dx, 1, d), b, dy, h1,
                           EpiStore{grad_y, dy, nullptr, 1.0f, 0}, st, "concat dY = dV W1y");
   if (rc) return rc;
-  rc = launch_gemm<float>(make_operand((const float*)p.du, 1, h1), make_operand(x, 1, dx), h1, dx, br,
-                          EpiStore{grad_w1, d, nullptr, 1.0f, 0}, st, "concat dW1x = dU^T X");
-  if (rc) return rc;
-  rc = launch_gemm<float>(make_operand((const float*)p.dv, 1, h1), make_operand(y, 1, dy), h1, dy, b,
-                          EpiStore{grad_w1 + dx, d, nullptr, 1.0f, 0}, st, "concat dW1y = dV^T Y");
-  if (rc) return rc;
+  // dW1x[h, a] = sum_i dU[i, h] X[i, a] and dW1y[h, a] = sum_j dV[j, h] Y[j, a]: K = batch -> split-K slabs, ordered reduce
+  {
+    EpiStore e{p.w1_slab, dx, nullptr, 1.0f, 0};
+    e.slab_stride = (int64_t)h1 * dx;
+    const int sx = (int)((br + p.w1_kchunk_x - 1) / p.w1_kchunk_x);
+    rc = launch_gemm<float>(make_operand((const float*)p.du, 1, h1), make_operand(x, 1, dx), h1, dx, br, e, st,
+                            "concat dW1x = dU^T X", sx, p.w1_kchunk_x);
+    if (rc) return rc;
+    {
+      ProfScope prof_("slab_reduce_ld_kernel", st);
+      hipLaunchKernelGGL(slab_reduce_ld_kernel, dim3(512), dim3(256), 0, st, (const float*)p.w1_slab, sx, (int64_t)h1, dx,
+                         grad_w1, d);
+    }
+    MI_LAUNCH_CHECK("slab_reduce_ld_kernel");
+    EpiStore e2{p.w1_slab, dy, nullptr, 1.0f, 0};
+    e2.slab_stride = (int64_t)h1 * dy;
+    const int sy = (int)((b + p.w1_kchunk_y - 1) / p.w1_kchunk_y);
+    rc = launch_gemm<float>(make_operand((const float*)p.dv, 1, h1), make_operand(y, 1, dy), h1, dy, b, e2, st,
+                            "concat dW1y = dV^T Y", sy, p.w1_kchunk_y);
+    if (rc) return rc;
+    {
+      ProfScope prof_("slab_reduce_ld_kernel", st);
+      hipLaunchKernelGGL(slab_reduce_ld_kernel, dim3(512), dim3(256), 0, st, (const float*)p.w1_slab, sy, (int64_t)h1, dy,
+                         grad_w1 + dx, d);
+    }
+    MI_LAUNCH_CHECK("slab_reduce_ld_kernel");
+  }
   {
     ProfScope prof_("colsum_kernel", st);
-    hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)((h1 + 63) / 64)), dim3(64), 0, st, (const float*)p.dv, b,
-                       (int64_t)h1, grad_b1);
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3((unsigned)((h1 + 63) / 64), 64), dim3(256), 0, st,
+                       (const float*)p.dv, b, (int64_t)h1, p.col_part);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)((h1 + 255) / 256)), dim3(256), 0, st,
+                       (const float*)p.col_part, 64, (int64_t)h1, grad_b1);
   }
   MI_LAUNCH_CHECK("colsum_kernel");
   return MI_OK;
@@ -223,10 +260,8 @@ extern "C" {
 
 size_t mi_concat_mlp_workspace_bytes(int64_t b_rows, int64_t b, int64_t d_img, int64_t d_txt, int64_t h1, int64_t h2,
                                      int precision, int need_grad) {
-  (void)d_img;
-  (void)d_txt;
   Workspace ws(nullptr, 0);
-  return plan_concat(ws, b_rows, b, h1, h2, precision, need_grad).bytes + 256;
+  return plan_concat(ws, b_rows, b, h1, h2, precision, need_grad, d_img > d_txt ? d_img : d_txt).bytes + 256;
 }
 
 int mi_concat_mlp_fwd(const float* x, const float* y, const float* w1, const float* b1, const float* w2, const float* b2,
@@ -240,7 +275,7 @@ int mi_concat_mlp_fwd(const float* x, const float* y, const float* w1, const flo
   if (rc) return rc;
   MI_CHECK_ARG(estimator == MI_DV || estimator == MI_INFONCE, "mi_concat_mlp_fwd: unknown estimator %d", estimator);
   Workspace ws(workspace, workspace_bytes);
-  ConcatPlan p = plan_concat(ws, b_rows, b, h1, h2, precision, need_grad);
+  ConcatPlan p = plan_concat(ws, b_rows, b, h1, h2, precision, need_grad, d_img > d_txt ? d_img : d_txt);
   if (!ws.ok()) {
     set_error("mi_concat_mlp_fwd: workspace too small (%zu < %zu)", workspace_bytes, ws.off);
     return MI_EWORKSPACE;
@@ -292,7 +327,7 @@ int mi_concat_mlp_bwd(const float* x, const float* y, const float* w1, const flo
   int rc = check_concat_shape("mi_concat_mlp_bwd", b_rows, b, row_offset, d_img, d_txt, h1, h2, precision);
   if (rc) return rc;
   Workspace ws(workspace, workspace_bytes);
-  ConcatPlan p = plan_concat(ws, b_rows, b, h1, h2, precision, 1);
+  ConcatPlan p = plan_concat(ws, b_rows, b, h1, h2, precision, 1, d_img > d_txt ? d_img : d_txt);
   if (!ws.ok()) {
     set_error("mi_concat_mlp_bwd: workspace too small (%zu < %zu): pass the workspace of the forward call made with "
               "need_grad = 1",

@@ -557,12 +557,28 @@ __global__ void slab_reduce_kernel(const float* __restrict__ slab, int n_slab, i
   }
 }
 
-// out[k] = sum_r m[r, k]  (one thread per column, rows in order: deterministic)
-__global__ void colsum_kernel(const float* __restrict__ m, int64_t rows, int64_t cols, float* __restrict__ out) {
+// column sums in two deterministic stages: grid (cols/64, 64 row chunks), 256 threads = 64 columns x 4 row groups
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ m, int64_t rows, int64_t cols,
+                                                             float* __restrict__ part /* [gridDim.y][cols] */) {
+  __shared__ float red[4][64];
+  const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
+  const int64_t k = (int64_t)blockIdx.x * 64 + cl;
+  const int64_t chunk = (rows + gridDim.y - 1) / gridDim.y;
+  const int64_t r0 = (int64_t)blockIdx.y * chunk;
+  int64_t r1 = r0 + chunk;
+  if (r1 > rows) r1 = rows;
+  float a = 0.0f;
+  if (k < cols)
+    for (int64_t r = r0 + rg; r < r1; r += 4) a += m[r * cols + k];
+  red[rg][cl] = a;
+  __syncthreads();
+  if (rg == 0 && k < cols) part[(int64_t)blockIdx.y * cols + k] = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
+}
+__global__ void colsum_final_kernel(const float* __restrict__ part, int n_part, int64_t cols, float* __restrict__ out) {
   const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= cols) return;
   float a = 0.0f;
-  for (int64_t r = 0; r < rows; ++r) a += m[r * cols + k];
+  for (int p = 0; p < n_part; ++p) a += part[(int64_t)p * cols + k];
   out[k] = a;
 }
 

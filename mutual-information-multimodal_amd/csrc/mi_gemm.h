@@ -157,7 +157,7 @@ __device__ __forceinline__ void foreach_acc(f32x16 (&acc)[2][2], int64_t m_base,
 
 template <typename OpT, typename TA, typename TB, class Epi>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(Operand<TA> A, Operand<TB> B, int64_t M, int64_t N, int64_t K,
-                                                      Epi epi) {
+                                                      int64_t k_chunk, Epi epi) {
   using Cfg = GemmCfg<OpT>;
   constexpr int KT = Cfg::KT, LD = Cfg::LD, KSTEP = Cfg::KSTEP;
   __shared__ __attribute__((aligned(16))) OpT As[kTile * LD];
@@ -177,10 +177,13 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(Operand<TA> A, Operand<TB>
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
 
   StageRegs<KT> ra, rb;
-  const int64_t nt = (K + KT - 1) / KT;
+  // split-K: blockIdx.z owns k in [kbeg, kend); the epilogue writes slab blockIdx.z
+  const int64_t kbeg = (int64_t)blockIdx.z * k_chunk;
+  const int64_t kend = (kbeg + k_chunk < K) ? kbeg + k_chunk : K;
+  const int64_t nt = (kend - kbeg + KT - 1) / KT;
   if (nt > 0) {
-    stage_load<TA, KT>(A, m0, 0, M, K, ra);
-    stage_load<TB, KT>(B, n0, 0, N, K, rb);
+    stage_load<TA, KT>(A, m0, kbeg, M, kend, ra);
+    stage_load<TB, KT>(B, n0, kbeg, N, kend, rb);
     stage_store<OpT, KT, LD>(A.mode, ra, As);
     stage_store<OpT, KT, LD>(B.mode, rb, Bs);
   }
@@ -188,8 +191,8 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(Operand<TA> A, Operand<TB>
   for (int64_t t = 0; t < nt; ++t) {
     const bool more = t + 1 < nt;
     if (more) {
-      stage_load<TA, KT>(A, m0, (t + 1) * KT, M, K, ra);
-      stage_load<TB, KT>(B, n0, (t + 1) * KT, N, K, rb);
+      stage_load<TA, KT>(A, m0, kbeg + (t + 1) * KT, M, kend, ra);
+      stage_load<TB, KT>(B, n0, kbeg + (t + 1) * KT, N, kend, rb);
     }
 #pragma unroll
     for (int kk = 0; kk < KT / KSTEP; ++kk) {
@@ -237,11 +240,13 @@ struct EpiStore {
   const float* bias;  // indexed by col, may be null
   float alpha;
   int accumulate;
+  int64_t slab_stride = 0;  // split-K: slab z at c + z * slab_stride
   __device__ __forceinline__ void operator()(f32x16 (&acc)[2][2], int64_t mb, int64_t nb, int64_t M, int64_t N) const {
+    float* cz = c + (int64_t)blockIdx.z * slab_stride;
     foreach_acc(acc, mb, nb, [&](int64_t row, int64_t col, float v) {
       if (row < M && col < N) {
         float o = alpha * v + (bias ? bias[col] : 0.0f);
-        float* dst = c + row * ldc + col;
+        float* dst = cz + row * ldc + col;
         if (accumulate) o += *dst;
         *dst = o;
       }
@@ -303,12 +308,13 @@ struct EpiGradScore {
 
 template <typename OpT, typename TA, typename TB, class Epi>
 static inline int launch_gemm(const Operand<TA>& A, const Operand<TB>& B, int64_t M, int64_t N, int64_t K,
-                              const Epi& epi, hipStream_t st, const char* what) {
+                              const Epi& epi, hipStream_t st, const char* what, int n_splits = 1, int64_t k_chunk = 0) {
   if (M <= 0 || N <= 0) return MI_OK;
-  dim3 grid((unsigned)((N + kTile - 1) / kTile), (unsigned)((M + kTile - 1) / kTile));
+  dim3 grid((unsigned)((N + kTile - 1) / kTile), (unsigned)((M + kTile - 1) / kTile), (unsigned)n_splits);
+  if (n_splits <= 1 || k_chunk <= 0) k_chunk = K > 0 ? K : 1;
   {
     ProfScope prof_(what, st);
-    hipLaunchKernelGGL((gemm_nt_kernel<OpT, TA, TB, Epi>), grid, dim3(256), 0, st, A, B, M, N, K, epi);
+    hipLaunchKernelGGL((gemm_nt_kernel<OpT, TA, TB, Epi>), grid, dim3(256), 0, st, A, B, M, N, K, k_chunk, epi);
   }
   MI_LAUNCH_CHECK(what);
   return MI_OK;

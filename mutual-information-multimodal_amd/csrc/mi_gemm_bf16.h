@@ -410,7 +410,7 @@ static inline int launch_gemm_bf16(const GemmBf16Args& args, int n_splits, const
 
 // ------------------------------------------------------------------------------------------------ prep kernels
 // in [R][C] fp32 -> out_rm [R][C] bf16 (optional) and out_t [C][R] bf16 (optional); 32 x 32 tiles through LDS
-__global__ __launch_bounds__(256) void cvt_transpose_kernel(const float* __restrict__ in, int64_t R, int64_t C,
+static __global__ __launch_bounds__(256) void cvt_transpose_kernel(const float* __restrict__ in, int64_t R, int64_t C,
                                                             bf16_t* __restrict__ out_rm, bf16_t* __restrict__ out_t) {
   __shared__ float tile[32][33];
   const int64_t r0 = (int64_t)blockIdx.y * 32, c0 = (int64_t)blockIdx.x * 32;
@@ -443,7 +443,7 @@ static inline int launch_cvt_transpose(const float* in, int64_t R, int64_t C, bf
 }
 
 // out[r][c] (ld = ldo) = sum_s slab[s][r][c]   (fixed order)
-__global__ void slab_reduce_ld_kernel(const float* __restrict__ slab, int n_slab, int64_t rows, int64_t cols,
+static __global__ void slab_reduce_ld_kernel(const float* __restrict__ slab, int n_slab, int64_t rows, int64_t cols,
                                       float* __restrict__ out, int64_t ldo) {
   const int64_t total = rows * cols;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
