@@ -123,7 +123,7 @@ class Stepper:
         self.y.requires_grad_(True)
         self.args = args
         self.graph = None
-        if world == 1:
+        if world == 1 and not os.environ.get("MI_BENCH_FORCE_DIST"):
             self._loss = lambda: mi_critics.fused_mi_bound(self.x, self.y, self.sid, self.critic, args.estimator,
                                                            precision=args.precision)
         else:
@@ -261,9 +261,11 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     group = None
-    if world > 1:
+    if world > 1 or os.environ.get("MI_BENCH_FORCE_DIST"):  # the latter: rehearse the RCCL path with one rank
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=device)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
         group = dist.group.WORLD
     if args.batch % world:
         raise SystemExit("--batch must be divisible by the number of GPUs")

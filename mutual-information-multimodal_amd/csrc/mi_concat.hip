@@ -6,8 +6,11 @@
 //             slab reductions / finish -> dX = dU W1x, dY = dV W1y, dW1 = [dU^T X | dV^T Y], db1 = colsum(dV)
 #include "mi_concat_bwd.h"
 #include "mi_concat_fwd.h"
+#include "mi_concat_fwd_dma.h"
 #include "mi_gemm.h"
 #include "mi_gemm_bf16.h"
+
+#include <stdlib.h>
 
 namespace mi {
 
@@ -116,15 +119,49 @@ template <typename OpT>
 static int launch_concat_fwd(const float* u, const float* v, const OpT* w2, const float* b2, const float* w3,
                              const float* b3, int64_t br, int64_t b, int h1, int h2, float* scores,
                              unsigned long long* bitsP, unsigned* bitsN, hipStream_t st) {
-  const size_t smem = sizeof(FwdSmem<OpT>);
-  hipError_t e = hipFuncSetAttribute((const void*)concat_fwd_kernel<OpT>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     (int)smem);
-  if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(concat_fwd_kernel)");
+  // NWN = 1: 256-thread workgroups, two per CU (independent barriers for the two waves of a SIMD); NWN = 2: one
+  // 512-thread workgroup per CU.  MI_CONCAT_FWD_NWN=2 selects the latter for A/B measurements.
+  static const int nwn = (getenv("MI_CONCAT_FWD_NWN") && atoi(getenv("MI_CONCAT_FWD_NWN")) == 2) ? 2 : 1;
   dim3 grid((unsigned)((b + kFwdTJ - 1) / kFwdTJ), (unsigned)((br + kFwdTI - 1) / kFwdTI));
-  {
+  if constexpr (sizeof(OpT) == 2) {
+    // bf16: LDS-DMA staged variant (mi_concat_fwd_dma.h); MI_CONCAT_FWD_REGSTAGE=1 selects the register-staged kernel
+    static const bool regstage = getenv("MI_CONCAT_FWD_REGSTAGE") != nullptr;
+    if (!regstage) {
+      if (nwn == 2) {
+        hipError_t e = hipFuncSetAttribute((const void*)concat_fwd_dma_kernel<2>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, FwdDmaSmem<2>::TOTAL);
+        if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(concat_fwd_dma_kernel)");
+        ProfScope prof_("concat_fwd_kernel", st);
+        hipLaunchKernelGGL((concat_fwd_dma_kernel<2>), grid, dim3(512), FwdDmaSmem<2>::TOTAL, st, u, v, w2, b2, w3, b3,
+                           br, b, h1, h2, scores, bitsP, bitsN);
+      } else {
+        hipError_t e = hipFuncSetAttribute((const void*)concat_fwd_dma_kernel<1>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, FwdDmaSmem<1>::TOTAL);
+        if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(concat_fwd_dma_kernel)");
+        ProfScope prof_("concat_fwd_kernel", st);
+        hipLaunchKernelGGL((concat_fwd_dma_kernel<1>), grid, dim3(256), FwdDmaSmem<1>::TOTAL, st, u, v, w2, b2, w3, b3,
+                           br, b, h1, h2, scores, bitsP, bitsN);
+      }
+      MI_LAUNCH_CHECK("concat_fwd_dma_kernel");
+      return MI_OK;
+    }
+  }
+  if (nwn == 2) {
+    const size_t smem = sizeof(FwdSmem<OpT, 2>);
+    hipError_t e = hipFuncSetAttribute((const void*)concat_fwd_kernel<OpT, 2>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(concat_fwd_kernel)");
     ProfScope prof_("concat_fwd_kernel", st);
-    hipLaunchKernelGGL(concat_fwd_kernel<OpT>, grid, dim3(512), smem, st, u, v, w2, b2, w3, b3, br, b, h1, h2, scores,
-                       bitsP, bitsN);
+    hipLaunchKernelGGL((concat_fwd_kernel<OpT, 2>), grid, dim3(512), smem, st, u, v, w2, b2, w3, b3, br, b, h1, h2,
+                       scores, bitsP, bitsN);
+  } else {
+    const size_t smem = sizeof(FwdSmem<OpT, 1>);
+    hipError_t e = hipFuncSetAttribute((const void*)concat_fwd_kernel<OpT, 1>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(concat_fwd_kernel)");
+    ProfScope prof_("concat_fwd_kernel", st);
+    hipLaunchKernelGGL((concat_fwd_kernel<OpT, 1>), grid, dim3(256), smem, st, u, v, w2, b2, w3, b3, br, b, h1, h2,
+                       scores, bitsP, bitsN);
   }
   MI_LAUNCH_CHECK("concat_fwd_kernel");
   return MI_OK;

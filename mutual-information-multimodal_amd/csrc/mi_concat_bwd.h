@@ -146,7 +146,17 @@ __global__ __launch_bounds__(512) void concat_bwd_duv_kernel(
   __syncthreads();
 
   for (int64_t j = jlo; j < jhi; j += kDuvTJ) {
-    // ---- (a) g tile and -V tile ---------------------------------------------------------------------------------
+    // ---- (a) sign words of this lane's two pairs: issued first, they fly while the g / -V tiles are staged ---------
+    unsigned long long words[2][4];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      const int64_t li = i0 + 8 * wave + 4 * m + (c >> 3), gj = j + (c & 7);
+      const bool ok = li < b_rows && gj < jhi;
+#pragma unroll
+      for (int pw = 0; pw < 4; ++pw)
+        words[m][pw] = (ok && pw < hw) ? bitsP[(li * b + gj) * wpp + h * hw + pw] : 0ull;
+    }
+    // ---- (b) g tile and -V tile -------------------------------------------------------------------------------------
     {
       const int il = tid >> 3, jl = tid & 7;
       const int64_t li = i0 + il, gj = j + jl;
@@ -162,22 +172,6 @@ __global__ __launch_bounds__(512) void concat_bwd_duv_kernel(
       }
     }
     __syncthreads();
-
-    // ---- (b) sign words of this lane's two pairs ----------------------------------------------------------------
-    unsigned long long words[2][4];
-#pragma unroll
-    for (int m = 0; m < 2; ++m) {
-      const int64_t li = i0 + 8 * wave + 4 * m + (c >> 3), gj = j + (c & 7);
-      const bool ok = li < b_rows && gj < jhi;
-#pragma unroll
-      for (int pw = 0; pw < 4; ++pw)
-        words[m][pw] = (ok && pw < hw) ? bitsP[(li * b + gj) * wpp + h * hw + pw] : 0ull;
-    }
-    float vn[4][NT];
-#pragma unroll
-    for (int jq = 0; jq < 4; ++jq)
-#pragma unroll
-      for (int ct = 0; ct < NT; ++ct) vn[jq][ct] = vneg[(jq + 4 * h) * KC + 32 * ct + c];
 
     // ---- (c) E[pair, k] = sum_n M[pair, n] W2w[n, k] on MFMA -------------------------------------------------------
     f32x16 acc[2][NT];
@@ -228,19 +222,23 @@ __global__ __launch_bounds__(512) void concat_bwd_duv_kernel(
     for (int jq = 0; jq < 4; ++jq)
 #pragma unroll
       for (int ct = 0; ct < NT; ++ct) dvp[jq][ct] = 0.0f;
+    // column-tile outermost: only 4 -V values are live at a time
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
+    for (int ct = 0; ct < NT; ++ct) {
+      float vn[4];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int is = r >> 2, jq = r & 3;  // row rho = jq + 8 is + 4 h  ->  local row 4m + is, local column jq + 4h
-        const float g = gs[(8 * wave + 4 * m + is) * kDuvTJ + jq + 4 * h];
+      for (int jq = 0; jq < 4; ++jq) vn[jq] = vneg[(jq + 4 * h) * KC + 32 * ct + c];
 #pragma unroll
-        for (int ct = 0; ct < NT; ++ct) {
-          const float e = (ureg[m][is][ct] > vn[jq][ct]) ? acc[m][ct][r] : 0.0f;
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int is = r >> 2, jq = r & 3;  // row rho = jq + 8 is + 4 h -> local row 4m + is, local column jq + 4h
+          const float g = gs[(8 * wave + 4 * m + is) * kDuvTJ + jq + 4 * h];
+          const float e = (ureg[m][is][ct] > vn[jq]) ? acc[m][ct][r] : 0.0f;
           duacc[m][is][ct] += g * e;
           dvp[jq][ct] += g * e;
         }
-      }
+    }
 
     // ---- (e) dV: deterministic cross-wave reduction (waves w and w+4 share a slot, in that order) -----------------
     if (wave < 4) {

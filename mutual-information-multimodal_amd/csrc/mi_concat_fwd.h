@@ -2,18 +2,24 @@
 //   reference: create_mi_pairs (main_utils.py:80-110) -> make_mlp(1536,[1024,512]) (model.py:18-32, main_utils.py:77)
 //   with the first Linear factorised: W1 [x_i ; y_j] + b1 = U_i + V_j, U = X W1x^T, V = Y W1y^T + b1.
 //
-// One 512-thread workgroup (8 waves, 2 per SIMD) owns a pair tile of 8 image rows x 32 text columns = 256 pairs and
-// runs H2/256 passes; in a pass it accumulates Z2^T[n, pair] for 256 hidden units n over all H1 = K:
+// A workgroup owns a pair tile of 8 image rows x 32 text columns = 256 pairs and runs H2 / (128 NWN) passes; in a pass it
+// accumulates Z2^T[n, pair] for 128 NWN hidden units n over all H1 = K:
 //     A operand (MFMA rows  = n)    : W2[n, k]  streamed HBM/L2 -> registers -> LDS (double-buffered k tiles)
 //     B operand (MFMA cols  = pair) : H1[pair, k] = relu(U_i[k] + V_j[k]) generated in registers from small U/V tiles
 // so the [B^2, H1] activation matrix of the reference (34 GB in bf16 at B = 4096) never exists.  The epilogue applies
 // relu and the dot with w3 in registers (b2 is the accumulator's initial value), and, when gradients are needed,
 // emits the sign pattern of Z2 as two bit images used by the backward kernels (1 bit per (pair, n), twice):
-//     bitsP: per pair, 64-bit words indexed [h][pass*2 + wn]; bit q = 16*a + r  <->  n = 256*pass + 128*wn + 32*a +
+//     bitsP: per pair, 64-bit words indexed [h][pw], pw = n / 128; bit q = 16*a + r  <->  n = 128*pw + 32*a +
 //            (r & 3) + 8*(r >> 2) + 4*h        (lane-local MFMA accumulator order; consumed by mi_concat_bwd dU/dV)
 //     bitsN: per (row i, 32-column block), one 32-bit word per n; bit q <-> column 32*block + q   (consumed by dW2)
 // Wave (wn, wp): hidden units [128 wn, +128) of the pass, pairs of local rows {2 wp, 2 wp + 1} x 32 columns:
 // 4 x 2 MFMA 32x32 tiles, 128 accumulator registers.
+//
+// NWN = 2: 512 threads, 256 hidden units per pass, ~100 KB of LDS -> one workgroup per CU (both waves of a SIMD belong
+//          to the same workgroup and run in lock-step between its barriers).
+// NWN = 1: 256 threads, 128 hidden units per pass, ~59 KB of LDS -> TWO workgroups per CU: the two waves of a SIMD
+//          belong to different workgroups with independent barriers, so one computes while the other waits.
+//          Same W2 bytes streamed per pair (each pass streams half the rows, twice as many passes).
 #pragma once
 #include <utility>
 
@@ -51,17 +57,17 @@ __device__ __forceinline__ void static_for(F&& f) {
 }
 constexpr int kFwdTI = 8;    // image rows per pair tile
 constexpr int kFwdTJ = 32;   // text columns per pair tile
-constexpr int kFwdNP = 256;  // hidden units per pass
 
-template <typename OpT>
+template <typename OpT, int NWN>
 struct FwdSmem {
   using Cfg = FwdCfg<OpT>;
-  OpT w[2][kFwdNP * Cfg::LDW];
+  static constexpr int NP = 128 * NWN;  // hidden units per pass
+  OpT w[2][NP * Cfg::LDW];
   float v[2][kFwdTJ * Cfg::LDUV];
   float u[2][kFwdTI * Cfg::LDUV];
-  float b2[kFwdNP];
-  float w3[kFwdNP];
-  float sred[2][2][kFwdTI * kFwdTJ];  // [pass parity is folded: accumulated][wn][pair]
+  float b2[NP];
+  float w3[NP];
+  float sred[2][kFwdTI * kFwdTJ];  // [wn][pair]
 };
 
 // relu(u + v) for 8 consecutive k, packed to bf16 (RNE).  relu on the packed pair as a signed 16-bit max with 0:
@@ -96,59 +102,74 @@ __device__ __forceinline__ unsigned ballot_to_lanes(unsigned word, unsigned long
   return word;
 }
 
-template <typename OpT>
-__global__ __launch_bounds__(512) void concat_fwd_kernel(const float* __restrict__ U, const float* __restrict__ V,
-                                                         const OpT* __restrict__ W2, const float* __restrict__ b2,
-                                                         const float* __restrict__ w3, const float* __restrict__ b3,
-                                                         int64_t b_rows, int64_t b, int H1, int H2,
-                                                         float* __restrict__ S, unsigned long long* __restrict__ bitsP,
-                                                         unsigned* __restrict__ bitsN) {
+template <typename OpT, int NWN>
+__global__ __launch_bounds__(256 * NWN, 2) /* 2 waves per SIMD: <= 256 registers */ void concat_fwd_kernel(const float* __restrict__ U, const float* __restrict__ V,
+                                                               const OpT* __restrict__ W2, const float* __restrict__ b2,
+                                                               const float* __restrict__ w3, const float* __restrict__ b3,
+                                                               int64_t b_rows, int64_t b, int H1, int H2,
+                                                               float* __restrict__ S,
+                                                               unsigned long long* __restrict__ bitsP,
+                                                               unsigned* __restrict__ bitsN) {
   using Cfg = FwdCfg<OpT>;
+  using Smem = FwdSmem<OpT, NWN>;
   constexpr int KT = Cfg::KT, KSTEP = Cfg::KSTEP, LDW = Cfg::LDW, LDUV = Cfg::LDUV;
+  constexpr int NTHR = 256 * NWN, NP = Smem::NP;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  FwdSmem<OpT>& sm = *reinterpret_cast<FwdSmem<OpT>*>(smem_raw);
+  Smem& sm = *reinterpret_cast<Smem*>(smem_raw);
 
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63;
   const int wn = wave >> 2, wp = wave & 3;
   const int c = lane & 31, h = lane >> 5;
   const int64_t i0 = (int64_t)blockIdx.y * kFwdTI, j0 = (int64_t)blockIdx.x * kFwdTJ;
-  const int n_pass = H2 / kFwdNP;
+  const int n_pass = H2 / NP;
   const int n_kt = H1 / KT;
   const int64_t JB = (b + 31) / 32;
 
   // ---- staging assignment (global -> registers -> LDS) ---------------------------------------------------------
-  // W2 tile: 256 rows x 128 bytes = 2048 16-byte vectors, 4 per thread.  V tile: 32 rows, U tile: 8 rows.
-  constexpr int VEC_PER_ROW_UV = KT / 4;  // float4 per U/V row
-  const bool has_v = tid < kFwdTJ * VEC_PER_ROW_UV;
-  const bool has_u = tid < kFwdTI * VEC_PER_ROW_UV;
-  const int uv_row = tid / VEC_PER_ROW_UV, uv_kv = tid % VEC_PER_ROW_UV;
-  int64_t vrow_g = j0 + uv_row;
-  if (vrow_g >= b) vrow_g = b - 1;  // clamp: the pair is discarded in the epilogue
-  int64_t urow_g = i0 + uv_row;
+  // W2 tile: NP rows x 128 bytes, 4 16-byte vectors per thread.  V tile: 32 rows, U tile: 8 rows of KT floats.
+  constexpr int VEC_UV = KT / 4;                                     // float4 per U/V row
+  constexpr int NV = (kFwdTJ * VEC_UV + NTHR - 1) / NTHR;            // V vectors per thread (1 or 2)
+  const bool has_u = tid < kFwdTI * VEC_UV;
+  const float* vsrc[NV];
+  int vdst[NV];
+  bool has_v[NV];
+#pragma unroll
+  for (int q = 0; q < NV; ++q) {
+    const int e = tid + NTHR * q;
+    has_v[q] = e < kFwdTJ * VEC_UV;
+    const int row = (e / VEC_UV) % kFwdTJ, kv = e % VEC_UV;
+    int64_t gj = j0 + row;
+    if (gj >= b) gj = b - 1;  // clamp: the pair is discarded in the epilogue
+    vsrc[q] = V + gj * H1 + kv * 4;
+    vdst[q] = row * LDUV + kv * 4;
+  }
+  const int u_row = (tid / VEC_UV) % kFwdTI, u_kv = tid % VEC_UV;
+  int64_t urow_g = i0 + u_row;
   if (urow_g >= b_rows) urow_g = b_rows - 1;
-  const float* vsrc = V + vrow_g * H1 + uv_kv * 4;
-  const float* usrc = U + urow_g * H1 + uv_kv * 4;
+  const float* usrc = U + urow_g * H1 + u_kv * 4;
 
   u32x4 rw[4];
-  f32x4 rv, ru;
+  f32x4 rv[NV], ru;
 
   auto stage_load = [&](int pass, int kt) {
     const int64_t k0 = (int64_t)kt * KT;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const int vidx = tid + 512 * q;
+      const int vidx = tid + NTHR * q;
       const int row = vidx >> 3, kv = vidx & 7;
-      const char* src = reinterpret_cast<const char*>(W2 + ((int64_t)(pass * kFwdNP + row)) * H1 + k0) + kv * 16;
+      const char* src = reinterpret_cast<const char*>(W2 + ((int64_t)(pass * NP + row)) * H1 + k0) + kv * 16;
       rw[q] = *reinterpret_cast<const u32x4*>(src);
     }
-    if (has_v) rv = *reinterpret_cast<const f32x4*>(vsrc + k0);
+#pragma unroll
+    for (int q = 0; q < NV; ++q)
+      if (has_v[q]) rv[q] = *reinterpret_cast<const f32x4*>(vsrc[q] + k0);
     if (has_u) ru = *reinterpret_cast<const f32x4*>(usrc + k0);
   };
   auto stage_store = [&](int buf) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const int vidx = tid + 512 * q;
+      const int vidx = tid + NTHR * q;
       const int row = vidx >> 3, kv = vidx & 7;
       if constexpr (sizeof(OpT) == 2) {
         *reinterpret_cast<u32x4*>(&sm.w[buf][row * LDW + kv * 8]) = rw[q];
@@ -161,17 +182,23 @@ __global__ __launch_bounds__(512) void concat_fwd_kernel(const float* __restrict
         }
       }
     }
-    if constexpr (sizeof(OpT) == 2) {
-      if (has_v) *reinterpret_cast<f32x4*>(&sm.v[buf][uv_row * LDUV + uv_kv * 4]) = rv;
-      if (has_u) *reinterpret_cast<f32x4*>(&sm.u[buf][uv_row * LDUV + uv_kv * 4]) = ru;
-    } else {
-      if (has_v) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) sm.v[buf][uv_row * LDUV + uv_kv * 4 + e] = rv[e];
+    for (int q = 0; q < NV; ++q) {
+      if (has_v[q]) {
+        if constexpr (sizeof(OpT) == 2) {
+          *reinterpret_cast<f32x4*>(&sm.v[buf][vdst[q]]) = rv[q];
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) sm.v[buf][vdst[q] + e] = rv[q][e];
+        }
       }
-      if (has_u) {
+    }
+    if (has_u) {
+      if constexpr (sizeof(OpT) == 2) {
+        *reinterpret_cast<f32x4*>(&sm.u[buf][u_row * LDUV + u_kv * 4]) = ru;
+      } else {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) sm.u[buf][uv_row * LDUV + uv_kv * 4 + e] = ru[e];
+        for (int e = 0; e < 4; ++e) sm.u[buf][u_row * LDUV + u_kv * 4 + e] = ru[e];
       }
     }
   };
@@ -180,10 +207,10 @@ __global__ __launch_bounds__(512) void concat_fwd_kernel(const float* __restrict
 
   for (int pass = 0; pass < n_pass; ++pass) {
     __syncthreads();  // every wave has left the previous pass's epilogue (it reads sm.w3)
-    // b2 / w3 of this pass's 256 hidden units
-    if (tid < kFwdNP) {
-      sm.b2[tid] = b2[pass * kFwdNP + tid];
-      sm.w3[tid] = w3[pass * kFwdNP + tid];
+    // b2 / w3 of this pass's hidden units
+    if (tid < NP) {
+      sm.b2[tid] = b2[pass * NP + tid];
+      sm.w3[tid] = w3[pass * NP + tid];
     }
     stage_load(pass, 0);
     __syncthreads();  // b2/w3 visible; previous pass's LDS reads finished
@@ -250,6 +277,7 @@ __global__ __launch_bounds__(512) void concat_fwd_kernel(const float* __restrict
     for (int t = 0; t < 2; ++t) {
       const int64_t li = i0 + 2 * wp + t;   // local image row of this pair tile
       const int64_t gj = j0 + c;            // text column of this lane
+      const int pw = pass * NWN + wn;       // 128-wide hidden-unit group
       float s = 0.0f;
       unsigned long long pbits = 0ull;
 #pragma unroll
@@ -268,11 +296,11 @@ __global__ __launch_bounds__(512) void concat_fwd_kernel(const float* __restrict
           }
         });
         if (bitsP && lane < 32 && li < b_rows)
-          bitsN[(li * JB + blockIdx.x) * H2 + pass * kFwdNP + wn * 128 + a * 32 + lane] = nword;
+          bitsN[(li * JB + blockIdx.x) * H2 + pw * 128 + a * 32 + lane] = nword;
       }
       if (bitsP && li < b_rows && gj < b) {
         const int64_t wpp = H2 / 64;  // 64-bit words per pair
-        bitsP[(li * b + gj) * wpp + h * (wpp / 2) + pass * 2 + wn] = pbits;
+        bitsP[(li * b + gj) * wpp + h * (wpp / 2) + pw] = pbits;
       }
       s_total[t] += s;
     }
@@ -282,13 +310,17 @@ __global__ __launch_bounds__(512) void concat_fwd_kernel(const float* __restrict
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
     float s = s_total[t] + __shfl_xor(s_total[t], 32);
-    if (h == 0) sm.sred[0][wn][(2 * wp + t) * 32 + c] = s;
+    if (h == 0) sm.sred[wn][(2 * wp + t) * 32 + c] = s;
   }
   __syncthreads();
   if (tid < kFwdTI * kFwdTJ) {
     const int il = tid >> 5, jl = tid & 31;
     const int64_t li = i0 + il, gj = j0 + jl;
-    if (li < b_rows && gj < b) S[li * b + gj] = (sm.sred[0][0][tid] + sm.sred[0][1][tid]) + b3[0];
+    if (li < b_rows && gj < b) {
+      float s = sm.sred[0][tid];
+      if (NWN == 2) s += sm.sred[1][tid];
+      S[li * b + gj] = s + b3[0];
+    }
   }
 }
 
