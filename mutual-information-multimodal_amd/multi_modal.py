@@ -32,7 +32,10 @@ def synthetic_embedding_source(args, device):
 
 def train_mutual_information(args, device):
     os.makedirs(args.save_directory, exist_ok=True)
-    logging.basicConfig(filename=os.path.join(args.save_directory, 'training_MI.log'), level=logging.INFO, filemode='w')
+    # same file name / mode as the reference (multi_modal.py:27-30); force=True so that an already configured root
+    # logger (a test runner, a notebook) does not silently swallow the training log
+    logging.basicConfig(filename=os.path.join(args.save_directory, 'training_MI.log'), level=logging.INFO, filemode='w',
+                        force=True)
     logging.getLogger(__name__).info(f"args: {vars(args)}")
     manager = MultiModalManager(d_img=args.embed_dim_img, d_txt=args.embed_dim_txt, critic=args.critic)
     losses = manager.train(synthetic_embedding_source(args, device), device, args)

@@ -461,3 +461,83 @@ def test_row_block_sharding_equals_full_batch(dev, critic, precision):
     for a, c in [(gx1, gxg), (gy1, gyg)] + list(zip(gp1, gpg)):
         scale = max(float(a.abs().max()), 1e-12)
         assert float((a - c).abs().max()) <= tol * scale + 1e-7
+
+
+# ------------------------------------------------------------------------------------------------ edge cases
+def test_fused_edge_cases(dev):
+    """Degenerate inputs the reference admits: all study ids equal (no negatives -> non-finite loss, as
+    logsumexp(empty) - log 0 in the reference), a single sample, extreme score magnitudes (LSE stability)."""
+    from mutual_info_img_txt import _hip, mi_critics
+    from mutual_info_img_txt.model import BilinearCritic
+    b, d = 16, 32
+    x, y, sid, params = orc.synthetic_case(b, d, d, h1=64, h2=256, salt=2)
+    mlp = _mlp_on(dev, 2 * d, (64, 256), params)
+    xd, yd = x.to(dev), y.to(dev)
+    for critic in (mlp, BilinearCritic(d, d).to(dev)):
+        with torch.no_grad():
+            loss = mi_critics.fused_mi_bound(xd, yd, ["same"] * b, critic, "dv", precision="f32")
+            assert not torch.isfinite(loss).all()
+            l1, st = mi_critics.fused_mi_bound(xd[:1], yd[:1], ["only"], critic, "infonce", precision="f32",
+                                               return_stats=True)
+            assert _hip.stats_dict(st)["n_neg"] == 0 and not torch.isfinite(l1).all()
+    # extreme magnitudes: scores of order +-1e3 must not overflow the log-sum-exp
+    big = BilinearCritic(d, d).to(dev)
+    with torch.no_grad():
+        big.weight.mul_(400.0)
+        loss, scores = mi_critics.fused_mi_bound(xd, yd, sid, big, "dv", precision="f32", return_scores=True)
+    ref = orc.bound_from_matrix(scores.cpu().double(), sid, "dv")
+    assert torch.isfinite(loss).all() and float(scores.abs().max()) > 300
+    assert abs(float(loss) - float(ref)) < 1e-3 * max(1.0, abs(float(ref)))
+
+
+def test_concat_properties_b1024(dev):
+    """Size-independent properties at a BASELINE-size hidden layer, bf16 mode."""
+    from mutual_info_img_txt import _hip, mi_critics
+    from mutual_info_img_txt.model import make_mlp
+    b, d = 1024, 128
+    gen = torch.Generator().manual_seed(5)
+    x = torch.randn(b, d, generator=gen).to(dev)
+    y = torch.randn(b, d, generator=gen).to(dev)
+    torch.manual_seed(5)
+    mlp = make_mlp(2 * d, [1024, 512]).to(dev)
+    sid = torch.arange(b, device=dev)
+    xl, yl = x.clone().requires_grad_(True), y.clone().requires_grad_(True)
+    dv = mi_critics.fused_mi_bound(xl, yl, sid, mlp, "dv", precision="bf16")
+    dv.sum().backward()
+    with torch.no_grad():
+        inf = mi_critics.fused_mi_bound(x, y, sid, mlp, "infonce", precision="bf16")
+        assert abs((float(inf) - float(dv.item())) - math.log(b * (b - 1))) < 1e-4
+        # shifting b3 shifts every score by a constant: loss unchanged
+        b3_saved = mlp[4].bias.detach().clone()
+        mlp[4].bias.add_(3.0)
+        inf2 = mi_critics.fused_mi_bound(x, y, sid, mlp, "infonce", precision="bf16")
+        mlp[4].bias.copy_(b3_saved)  # restore exactly ((b + 3) - 3 != b in floating point)
+        assert abs(float(inf2) - float(inf)) < 2e-4
+        # one shared study id removes exactly two negatives
+        sid2 = sid.clone()
+        sid2[3] = sid2[700]
+        _, st = mi_critics.fused_mi_bound(x, y, sid2, mlp, "dv", precision="bf16", return_stats=True)
+        assert _hip.stats_dict(st)["n_neg"] == b * (b - 1) - 2
+    # d loss / d b3 = sum of all d loss / d score = (+1) + (-1)
+    assert abs(float(mlp[4].bias.grad)) < 1e-4
+    # bit-reproducible gradients (slab reductions in a fixed order, no float atomics)
+    g1 = [p.grad.clone() for p in mlp.parameters()] + [xl.grad.clone(), yl.grad.clone()]
+    mlp.zero_grad()
+    xl.grad = None
+    yl.grad = None
+    mi_critics.fused_mi_bound(xl, yl, sid, mlp, "dv", precision="bf16").sum().backward()
+    g2 = [p.grad for p in mlp.parameters()] + [xl.grad, yl.grad]
+    assert all(torch.equal(a, c) for a, c in zip(g1, g2))
+
+
+def test_train_synthetic_entry_point(dev, tmp_path):
+    """train.py --synthetic (the reference's train_MI_models entry point, train.py:21-36) on the fused path: the
+    bound improves (the loss falls) on correlated synthetic embeddings."""
+    import train
+    losses = train.train_MI_models(["--synthetic", "--batch_size", "64", "--num_train_epochs", "3", "--steps_per_epoch",
+                                    "15", "--critic", "concat_mlp", "--embed_dim_img", "32", "--embed_dim_txt", "32",
+                                    "--init_lr", "1e-3", "--save_directory", str(tmp_path), "--precision", "f32"])
+    assert len(losses) == 3 and all(math.isfinite(v) for v in losses)
+    assert losses[-1] < losses[0]
+    log = open(next(p for p in tmp_path.rglob("training_MI.log"))).read()
+    assert "Epoch 1 loss = " in log and "Epoch 1 took " in log  # the reference's two log lines (main_utils.py:251-252)
