@@ -3,6 +3,7 @@
 // HBM-bound kernels: the forward reads 4 bytes per logit once, the backward reads 4 and writes 4.
 // Reductions are two-stage and merged in a fixed order (no float atomics): results are bit-reproducible.
 #include <stdarg.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <vector>
@@ -33,6 +34,10 @@ static bool g_prof_on = false;
 static std::vector<ProfEntry> g_prof;
 static std::vector<hipEvent_t> g_prof_pool;
 bool profile_enabled() { return g_prof_on; }
+int xcd_natural() {
+  static const int v = getenv("MI_XCD_NATURAL") ? 1 : 0;
+  return v;
+}
 static hipEvent_t prof_event() {
   if (!g_prof_pool.empty()) {
     hipEvent_t e = g_prof_pool.back();

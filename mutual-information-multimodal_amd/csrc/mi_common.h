@@ -152,6 +152,26 @@ __device__ __forceinline__ int pair_kind(int64_t gi, int64_t gj, int64_t sid_i, 
   return sid_i != sid_j ? 2 : 0;
 }
 
+// XCD affinity for 1-D grids (speed only, never correctness: guide T1 / section 6 G16).  Workgroups are dealt
+// round-robin over the 8 XCDs in dispatch order, each XCD has a private L2: workgroup L runs on XCD L % 8 and is the
+// (L / 8)-th workgroup of that XCD.  Work items that share operand panels get the same `outer` index and run back to
+// back on one XCD:  inner = (L / 8) % n_inner,  outer = (L % 8) + 8 * ((L / 8) / n_inner).
+// Launch 8 * n_inner * ceil(n_outer / 8) workgroups; returns false for the padding ones.
+__device__ __forceinline__ bool xcd_decode(int n_inner, int n_outer, int& inner, int& outer, int natural = 0) {
+  const int L = (int)blockIdx.x, e = L & 7, q = L >> 3;
+  if (natural) {  // A/B switch: plain row-major order
+    inner = L % n_inner;
+    outer = L / n_inner;
+    return outer < n_outer;
+  }
+  inner = q % n_inner;
+  outer = e + 8 * (q / n_inner);
+  return outer < n_outer;
+}
+// MI_XCD_NATURAL=1 in the environment selects the natural order in every kernel that uses xcd_decode (A/B runs)
+int xcd_natural();
+static inline unsigned xcd_grid(int64_t n_inner, int64_t n_outer) { return (unsigned)(8 * n_inner * ((n_outer + 7) / 8)); }
+
 // launchers shared between translation units --------------------------------------------------------
 // partials[n_partials] -> stats, loss_out (one workgroup).  local_record (optional, 8 floats) receives the
 // merged (m, s, pos, cnt_lo, cnt_hi) for the cross-rank merge.

@@ -123,6 +123,8 @@ static int launch_concat_fwd(const float* u, const float* v, const OpT* w2, cons
   // 512-thread workgroup per CU.  MI_CONCAT_FWD_NWN=2 selects the latter for A/B measurements.
   static const int nwn = (getenv("MI_CONCAT_FWD_NWN") && atoi(getenv("MI_CONCAT_FWD_NWN")) == 2) ? 2 : 1;
   dim3 grid((unsigned)((b + kFwdTJ - 1) / kFwdTJ), (unsigned)((br + kFwdTI - 1) / kFwdTI));
+  // the LDS-DMA kernel decodes an XCD-aware tile order from a 1-D grid
+  const dim3 grid1d((unsigned)(8 * (((b + kFwdTJ - 1) / kFwdTJ + 7) / 8) * ((br + kFwdTI - 1) / kFwdTI)));
   if constexpr (sizeof(OpT) == 2) {
     // bf16: LDS-DMA staged variant (mi_concat_fwd_dma.h); MI_CONCAT_FWD_REGSTAGE=1 selects the register-staged kernel
     static const bool regstage = getenv("MI_CONCAT_FWD_REGSTAGE") != nullptr;
@@ -132,15 +134,15 @@ static int launch_concat_fwd(const float* u, const float* v, const OpT* w2, cons
                                            hipFuncAttributeMaxDynamicSharedMemorySize, FwdDmaSmem<2>::TOTAL);
         if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(concat_fwd_dma_kernel)");
         ProfScope prof_("concat_fwd_kernel", st);
-        hipLaunchKernelGGL((concat_fwd_dma_kernel<2>), grid, dim3(512), FwdDmaSmem<2>::TOTAL, st, u, v, w2, b2, w3, b3,
-                           br, b, h1, h2, scores, bitsP, bitsN);
+        hipLaunchKernelGGL((concat_fwd_dma_kernel<2>), grid1d, dim3(512), FwdDmaSmem<2>::TOTAL, st, u, v, w2, b2, w3, b3,
+                           br, b, h1, h2, scores, bitsP, bitsN, xcd_natural());
       } else {
         hipError_t e = hipFuncSetAttribute((const void*)concat_fwd_dma_kernel<1>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, FwdDmaSmem<1>::TOTAL);
         if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(concat_fwd_dma_kernel)");
         ProfScope prof_("concat_fwd_kernel", st);
-        hipLaunchKernelGGL((concat_fwd_dma_kernel<1>), grid, dim3(256), FwdDmaSmem<1>::TOTAL, st, u, v, w2, b2, w3, b3,
-                           br, b, h1, h2, scores, bitsP, bitsN);
+        hipLaunchKernelGGL((concat_fwd_dma_kernel<1>), grid1d, dim3(256), FwdDmaSmem<1>::TOTAL, st, u, v, w2, b2, w3, b3,
+                           br, b, h1, h2, scores, bitsP, bitsN, xcd_natural());
       }
       MI_LAUNCH_CHECK("concat_fwd_dma_kernel");
       return MI_OK;
@@ -191,12 +193,12 @@ static int concat_bwd_impl(const float* x, const float* y, const float* w1, cons
     hipError_t e = hipFuncSetAttribute((const void*)concat_bwd_duv_kernel<OpT>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(concat_bwd_duv_kernel)");
-    dim3 grid((unsigned)((h1 + DC::KC - 1) / DC::KC), (unsigned)p.n_iblk, (unsigned)p.n_jsplit);
+    dim3 grid(xcd_grid((h1 + DC::KC - 1) / DC::KC, (int64_t)p.n_iblk * p.n_jsplit));
     {
       ProfScope prof_("concat_bwd_duv_kernel", st);
       hipLaunchKernelGGL(concat_bwd_duv_kernel<OpT>, grid, dim3(512), smem, st, (const float*)p.u, (const float*)p.v,
                          (const OpT*)w2wp, (const unsigned long long*)p.bitsP, scores, sid_rows, sid_cols, stats,
-                         grad_out, br, b, row_offset, h1, h2, p.cols_per_split, p.du_slab, p.dv_slab);
+                         grad_out, br, b, row_offset, h1, h2, p.cols_per_split, xcd_natural(), p.du_slab, p.dv_slab);
     }
     MI_LAUNCH_CHECK("concat_bwd_duv_kernel");
     {
@@ -215,12 +217,12 @@ static int concat_bwd_impl(const float* x, const float* y, const float* w1, cons
     hipError_t e = hipFuncSetAttribute((const void*)concat_bwd_dw2_kernel<OpT>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(concat_bwd_dw2_kernel)");
-    dim3 grid((unsigned)((h1 + 255) / 256), (unsigned)(h2 / 256), (unsigned)p.n_dsplit);
+    dim3 grid(xcd_grid(((h1 + 255) / 256) * (h2 / 256), p.n_dsplit));
     {
       ProfScope prof_("concat_bwd_dw2_kernel", st);
       hipLaunchKernelGGL(concat_bwd_dw2_kernel<OpT>, grid, dim3(512), smem, st, (const float*)p.u, (const float*)p.v,
                          (const unsigned*)p.bitsN, scores, sid_rows, sid_cols, stats, grad_out, br, b, row_offset, h1,
-                         h2, p.rows_per_dsplit, p.d_slab);
+                         h2, p.rows_per_dsplit, xcd_natural(), p.d_slab);
     }
     MI_LAUNCH_CHECK("concat_bwd_dw2_kernel");
     const size_t smem2 = (size_t)((b + 31) / 32) * 32 * sizeof(float);

@@ -70,7 +70,7 @@ __global__ __launch_bounds__(512) void concat_bwd_duv_kernel(
     const float* __restrict__ U, const float* __restrict__ V, const OpT* __restrict__ W2wP,
     const unsigned long long* __restrict__ bitsP, const float* __restrict__ S, const int64_t* __restrict__ sid_rows,
     const int64_t* __restrict__ sid_cols, const mi_stats* __restrict__ stats, const float* __restrict__ grad_out,
-    int64_t b_rows, int64_t b, int64_t row_offset, int H1, int H2, int cols_per_split,
+    int64_t b_rows, int64_t b, int64_t row_offset, int H1, int H2, int cols_per_split, int natural_order,
     float* __restrict__ dUslab /* [n_jsplit][b_rows][H1] */, float* __restrict__ dVslab /* [n_iblk][b][H1] */) {
   using Cfg = DuvCfg<OpT>;
   constexpr int KC = Cfg::KC, NT = Cfg::NT;
@@ -89,9 +89,15 @@ __global__ __launch_bounds__(512) void concat_bwd_duv_kernel(
 
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int c = lane & 31, h = lane >> 5;
-  const int kc0 = blockIdx.x * KC;
-  const int64_t i0 = (int64_t)blockIdx.y * kDuvTI;
-  const int64_t jlo = (int64_t)blockIdx.z * cols_per_split;
+  // XCD-aware order: the k chunks of one (row block, column split) run back to back on one XCD and share its sign words
+  const int n_kc = (H1 + KC - 1) / KC, n_iblk = (int)((b_rows + kDuvTI - 1) / kDuvTI);
+  const int n_js = (int)((b + cols_per_split - 1) / cols_per_split);
+  int kci, oi;
+  if (!xcd_decode(n_kc, n_iblk * n_js, kci, oi, natural_order)) return;
+  const int iblk = oi % n_iblk, jsp = oi / n_iblk;
+  const int kc0 = kci * KC;
+  const int64_t i0 = (int64_t)iblk * kDuvTI;
+  const int64_t jlo = (int64_t)jsp * cols_per_split;
   int64_t jhi = jlo + cols_per_split;
   if (jhi > b) jhi = b;
   const int wpp = H2 / 64, hw = wpp / 2;  // 64-bit words per pair, per lane half
@@ -261,7 +267,7 @@ __global__ __launch_bounds__(512) void concat_bwd_duv_kernel(
       if (gj < jhi && kc0 + kk < H1) {
         const float v = ((dvred[(0 * kDuvTJ + jl) * KC + kk] + dvred[(1 * kDuvTJ + jl) * KC + kk]) +
                          dvred[(2 * kDuvTJ + jl) * KC + kk]) + dvred[(3 * kDuvTJ + jl) * KC + kk];
-        dVslab[((int64_t)blockIdx.y * b + gj) * H1 + kc0 + kk] = v;
+        dVslab[((int64_t)iblk * b + gj) * H1 + kc0 + kk] = v;
       }
     }
     __syncthreads();  // gs / vneg / dvred are rewritten by the next step
@@ -277,7 +283,7 @@ __global__ __launch_bounds__(512) void concat_bwd_duv_kernel(
       for (int ct = 0; ct < NT; ++ct) {
         const float v = duacc[m][is][ct] + __shfl_xor(duacc[m][is][ct], 32);
         if (h == 0 && li < b_rows && kc0 + 32 * ct + c < H1)
-          dUslab[((int64_t)blockIdx.z * b_rows + li) * H1 + kc0 + 32 * ct + c] = v;
+          dUslab[((int64_t)jsp * b_rows + li) * H1 + kc0 + 32 * ct + c] = v;
       }
     }
 }
@@ -291,7 +297,7 @@ __global__ __launch_bounds__(512) void concat_bwd_dw2_kernel(
     const float* __restrict__ U, const float* __restrict__ V, const unsigned* __restrict__ bitsN,
     const float* __restrict__ S, const int64_t* __restrict__ sid_rows, const int64_t* __restrict__ sid_cols,
     const mi_stats* __restrict__ stats, const float* __restrict__ grad_out, int64_t b_rows, int64_t b,
-    int64_t row_offset, int H1, int H2, int rows_per_split, float* __restrict__ Dslab) {
+    int64_t row_offset, int H1, int H2, int rows_per_split, int natural_order, float* __restrict__ Dslab) {
   constexpr bool kBf16 = sizeof(OpT) == 2;
   constexpr int LDV = 36;  // floats per k row of the transposed V tile (32 columns + pad: conflict-free b128)
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -302,8 +308,13 @@ __global__ __launch_bounds__(512) void concat_bwd_dw2_kernel(
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int wn = wave >> 2, wk = wave & 3;
   const int c = lane & 31, h = lane >> 5;
-  const int kb0 = blockIdx.x * 256, nb0 = blockIdx.y * 256;
-  const int64_t ilo = (int64_t)blockIdx.z * rows_per_split;
+  // XCD-aware order: the (k block, n block) tiles of one row split run on one XCD and share its sign words, U, V, S
+  const int n_kb = (H1 + 255) / 256, n_nb = H2 / 256;
+  const int n_split = (int)((b_rows + rows_per_split - 1) / rows_per_split);
+  int tile, zsp;
+  if (!xcd_decode(n_kb * n_nb, n_split, tile, zsp, natural_order)) return;
+  const int kb0 = (tile % n_kb) * 256, nb0 = (tile / n_kb) * 256;
+  const int64_t ilo = (int64_t)zsp * rows_per_split;
   int64_t ihi = ilo + rows_per_split;
   if (ihi > b_rows) ihi = b_rows;
   const int64_t JB = (b + 31) / 32;
@@ -433,7 +444,7 @@ __global__ __launch_bounds__(512) void concat_bwd_dw2_kernel(
   }
 
   // ---- store the partial D tile (rows n = registers, columns k = lanes) -------------------------------------------
-  float* out = Dslab + (int64_t)blockIdx.z * H2 * H1;
+  float* out = Dslab + (int64_t)zsp * H2 * H1;
 #pragma unroll
   for (int a = 0; a < 4; ++a)
 #pragma unroll

@@ -34,7 +34,7 @@ template <int NWN>
 __global__ __launch_bounds__(256 * NWN, 2) void concat_fwd_dma_kernel(
     const float* __restrict__ U, const float* __restrict__ V, const bf16_t* __restrict__ W2, const float* __restrict__ b2,
     const float* __restrict__ w3, const float* __restrict__ b3, int64_t b_rows, int64_t b, int H1, int H2,
-    float* __restrict__ S, unsigned long long* __restrict__ bitsP, unsigned* __restrict__ bitsN) {
+    float* __restrict__ S, unsigned long long* __restrict__ bitsP, unsigned* __restrict__ bitsN, int natural_order) {
   using L = FwdDmaSmem<NWN>;
   constexpr int NP = L::NP, NWAVES = 4 * NWN;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -46,7 +46,18 @@ __global__ __launch_bounds__(256 * NWN, 2) void concat_fwd_dma_kernel(
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const int wn = wave >> 2, wp = wave & 3;
   const int c = lane & 31, h = lane >> 5;
-  const int64_t i0 = (int64_t)blockIdx.y * kFwdTI, j0 = (int64_t)blockIdx.x * kFwdTJ;
+  // XCD-aware tile order: XCD e owns the column tiles jt = e + 8 m and sweeps the row tiles with them, so its share of
+  // V (one eighth of it) stays in its L2 for the whole launch and U is read from HBM once per XCD.
+  const int n_jt = (int)((b + kFwdTJ - 1) / kFwdTJ), n_it = (int)((b_rows + kFwdTI - 1) / kFwdTI);
+  const int njx = (n_jt + 7) / 8;
+  int jt = (int)(blockIdx.x & 7) + 8 * (int)((blockIdx.x >> 3) % njx);
+  int it = (int)((blockIdx.x >> 3) / njx);
+  if (natural_order) {
+    jt = (int)(blockIdx.x % (8 * njx));
+    it = (int)(blockIdx.x / (8 * njx));
+  }
+  if (jt >= n_jt || it >= n_it) return;
+  const int64_t i0 = (int64_t)it * kFwdTI, j0 = (int64_t)jt * kFwdTJ;
   const int n_pass = H2 / NP;
   const int n_kt = H1 / 64;
   const int64_t JB = (b + 31) / 32;
@@ -193,7 +204,7 @@ __global__ __launch_bounds__(256 * NWN, 2) void concat_fwd_dma_kernel(
           }
         });
         if (bitsP && lane < 32 && li < b_rows)
-          bitsN[(li * JB + blockIdx.x) * H2 + pw * 128 + a * 32 + lane] = nword;
+          bitsN[(li * JB + jt) * H2 + pw * 128 + a * 32 + lane] = nword;
       }
       if (bitsP && li < b_rows && gj < b) {
         const int64_t wpp = H2 / 64;
