@@ -84,11 +84,11 @@ static GemmBf16Args one_problem(const bf16_t* a, int64_t lda, const bf16_t* b, i
 // ------------------------------------------------------------------------------------------------ fast path
 static int fast_prep_and_t(const float* x, const float* y, const float* w, int64_t br, int64_t b, int64_t dx, int64_t dy,
                            const BilinearPlan& p, hipStream_t st) {
-  int rc = launch_cvt_transpose(x, br, dx, p.xb, p.xtb, st, "bilinear prep X");
-  if (rc) return rc;
-  rc = launch_cvt_transpose(y, b, dy, p.yb, p.ytb, st, "bilinear prep Y");
-  if (rc) return rc;
-  rc = launch_cvt_transpose(w, dx, dy, p.wb, p.wtb, st, "bilinear prep W");
+  CvtJobs jobs{};
+  jobs.j[0] = CvtJob{x, br, dx, p.xb, p.xtb};
+  jobs.j[1] = CvtJob{y, b, dy, p.yb, p.ytb};
+  jobs.j[2] = CvtJob{w, dx, dy, p.wb, p.wtb};
+  int rc = launch_cvt_transpose3(jobs, st, "bilinear prep X Y W");
   if (rc) return rc;
   // T[i, c] = sum_a X[i, a] W[a, c]: A = Xb [br][dx], B = W^T [dy][dx]
   EpiStoreMulti e{};

@@ -466,6 +466,52 @@ static inline int launch_cvt_transpose(const float* in, int64_t R, int64_t C, bf
   return MI_OK;
 }
 
+// up to three conversions in one launch (blockIdx.z selects the job; the grid covers the largest one)
+struct CvtJob {
+  const float* in;
+  int64_t R, C;
+  bf16_t* out_rm;
+  bf16_t* out_t;
+};
+struct CvtJobs {
+  CvtJob j[3];
+};
+static __global__ __launch_bounds__(256) void cvt_transpose3_kernel(CvtJobs jobs) {
+  __shared__ float tile[32][33];
+  const CvtJob& J = jobs.j[blockIdx.z];
+  const int64_t r0 = (int64_t)blockIdx.y * 32, c0 = (int64_t)blockIdx.x * 32;
+  if (r0 >= J.R || c0 >= J.C) return;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int64_t r = r0 + ty + 8 * q, c = c0 + tx;
+    const float v = (r < J.R && c < J.C) ? J.in[r * J.C + c] : 0.0f;
+    tile[ty + 8 * q][tx] = v;
+    if (J.out_rm && r < J.R && c < J.C) J.out_rm[r * J.C + c] = (bf16_t)v;
+  }
+  if (!J.out_t) return;
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int64_t c = c0 + ty + 8 * q, r = r0 + tx;
+    if (c < J.C && r < J.R) J.out_t[c * J.R + r] = (bf16_t)tile[tx][ty + 8 * q];
+  }
+}
+static inline int launch_cvt_transpose3(const CvtJobs& jobs, hipStream_t st, const char* what) {
+  int64_t rmax = 0, cmax = 0;
+  for (int q = 0; q < 3; ++q) {
+    if (jobs.j[q].R > rmax) rmax = jobs.j[q].R;
+    if (jobs.j[q].C > cmax) cmax = jobs.j[q].C;
+  }
+  dim3 grid((unsigned)((cmax + 31) / 32), (unsigned)((rmax + 31) / 32), 3);
+  {
+    ProfScope prof_(what, st);
+    hipLaunchKernelGGL(cvt_transpose3_kernel, grid, dim3(256), 0, st, jobs);
+  }
+  MI_LAUNCH_CHECK(what);
+  return MI_OK;
+}
+
 // out[r][c] (ld = ldo) = sum_s slab[s][r][c]   (fixed order)
 static __global__ void slab_reduce_ld_kernel(const float* __restrict__ slab, int n_slab, int64_t rows, int64_t cols,
                                       float* __restrict__ out, int64_t ldo) {
