@@ -105,7 +105,8 @@ static int bilinear_fwd_fast(const float* x, const float* y, const float* w, con
   rc = launch_gemm_bf16(one_problem(p.tb, dy, p.yb, dy, br, b, dy), 1,
                         EpiScoreLse2{sid_rows, sid_cols, row_offset, scores_out, p.partials}, st, "bilinear score+LSE");
   if (rc) return rc;
-  return launch_finalize(p.partials, p.n_partials, b, estimator, loss_out, stats, partials_out, st);
+  // the launcher picks 256 x 256 tiles for large score matrices: fewer partials than the plan reserved
+  return launch_finalize(p.partials, gemm_bf16_n_partials(br, b, dy), b, estimator, loss_out, stats, partials_out, st);
 }
 
 static int bilinear_bwd_fast(const int64_t* sid_rows, const int64_t* sid_cols, int64_t br, int64_t b, int64_t row_offset,

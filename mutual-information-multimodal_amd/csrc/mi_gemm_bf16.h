@@ -91,21 +91,91 @@ __device__ __forceinline__ void store4_transposed(bf16_t* dst_t, int64_t ld_t, i
   }
 }
 
+// Wave-private LDS staging area of the epilogues (free once the K loop's last barrier has passed)
+constexpr int kEpiPitch = 144;                    // bytes per staged row: 64 bf16 + 16 bytes of padding
+constexpr int kEpiLdsPerWave = 64 * kEpiPitch;    // 9,216 bytes
+
+__device__ __forceinline__ void wave_lds_fence() {
+  // LDS operations of one wave execute in order; this only stops the compiler from moving them across
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
+// Store a wave's 64 x 64 tile (fp32, MFMA accumulator layout) as bf16 -- row-major into rm[(mb + r) * ld_rm + nb + c]
+// and / or transposed into tr[(nb + c) * ld_tr + mb + r] -- through the wave's LDS staging area, so that every global
+// store is a 16-byte chunk of a 128-byte row segment (the direct accumulator-layout stores are 2-byte / strided 8-byte
+// writes).  Needs ld_rm % 8 == 0 (ld_tr % 8 == 0) and 16-byte aligned bases; elements beyond M x N are dropped, which
+// with N % 8 == 0 (M % 8 == 0) happens in whole chunks.
+__device__ __forceinline__ void wave_tile_store_bf16(f32x16 (&acc)[2][2], char* lds, bf16_t* rm, int64_t ld_rm,
+                                                     bf16_t* tr, int64_t ld_tr, int64_t mb, int64_t nb, int64_t M,
+                                                     int64_t N) {
+  const int lane = threadIdx.x & 63;
+  const int col_l = lane & 31, half = lane >> 5;
+  const int srow = lane >> 3, chunk = lane & 7;
+  if (rm) {
+    wave_lds_fence();
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+      for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row_l = tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+          *reinterpret_cast<bf16_t*>(lds + row_l * kEpiPitch + (tn * 32 + col_l) * 2) = (bf16_t)acc[tm][tn][r];
+        }
+    wave_lds_fence();
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int row_l = it * 8 + srow;
+      const bf16x8 v = *reinterpret_cast<const bf16x8*>(lds + row_l * kEpiPitch + chunk * 16);
+      const int64_t grow = mb + row_l, gcol = nb + chunk * 8;
+      if (grow < M && gcol < N) *reinterpret_cast<bf16x8*>(rm + grow * ld_rm + gcol) = v;
+    }
+  }
+  if (tr) {
+    wave_lds_fence();
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+      for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int row0_l = tm * 32 + 8 * g + 4 * half;
+          const bf16x4 v = {(bf16_t)acc[tm][tn][4 * g], (bf16_t)acc[tm][tn][4 * g + 1], (bf16_t)acc[tm][tn][4 * g + 2],
+                            (bf16_t)acc[tm][tn][4 * g + 3]};
+          *reinterpret_cast<bf16x4*>(lds + (tn * 32 + col_l) * kEpiPitch + row0_l * 2) = v;
+        }
+    wave_lds_fence();
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int c_l = it * 8 + srow;
+      const bf16x8 v = *reinterpret_cast<const bf16x8*>(lds + c_l * kEpiPitch + chunk * 16);
+      const int64_t gcol = nb + c_l, grow = mb + chunk * 8;
+      if (gcol < N && grow < M) *reinterpret_cast<bf16x8*>(tr + gcol * ld_tr + grow) = v;
+    }
+  }
+}
+
 struct EpiStoreMulti {
+  static constexpr bool kReducesPartial = false;
   EpiOut out[2];
   __device__ __forceinline__ void operator()(f32x16 (&acc)[2][2], int64_t mb, int64_t nb, int64_t M, int64_t N, int prob,
-                                             int zsplit) const {
+                                             int zsplit, char* lds) const {
     const EpiOut& o = out[prob];
-    if (o.f32 || o.bf) {
+    const bool staged = (M % 8 == 0) && (N % 8 == 0) && (!o.bf || o.ld_bf % 8 == 0) && (!o.bf_t || o.ld_bf_t % 8 == 0);
+    if (o.f32 || (o.bf && !staged)) {
       float* f = o.f32 ? o.f32 + (int64_t)zsplit * o.slab_stride : nullptr;
+      bf16_t* bfd = staged ? nullptr : o.bf;
       foreach_acc(acc, mb, nb, [&](int64_t row, int64_t col, float v) {
         if (row < M && col < N) {
           if (f) f[row * o.ld_f32 + col] = v;
-          if (o.bf) o.bf[row * o.ld_bf + col] = (bf16_t)v;
+          if (bfd) bfd[row * o.ld_bf + col] = (bf16_t)v;
         }
       });
     }
-    if (o.bf_t) {
+    if (staged) {
+      if (o.bf || o.bf_t) wave_tile_store_bf16(acc, lds, o.bf, o.ld_bf, o.bf_t, o.ld_bf_t, mb, nb, M, N);
+    } else if (o.bf_t) {
       foreach_acc4(acc, mb, nb, [&](int64_t row0, int64_t col, float v0, float v1, float v2, float v3) {
         if (col < N) store4_transposed(o.bf_t, o.ld_bf_t, row0, col, M, v0, v1, v2, v3);
       });
@@ -120,41 +190,71 @@ struct EpiScoreLse2 {
   int64_t row_offset;
   float* scores;
   Partial* partials;
-  __device__ __forceinline__ void operator()(f32x16 (&acc)[2][2], int64_t mb, int64_t nb, int64_t M, int64_t N, int,
-                                             int) const {
-    // Two passes over the 64 accumulators of this lane: the maximum of its negatives first, then one hardware
-    // exponential (v_exp_f32) per negative -- no data-dependent rescale branch (bf16 mode: the scores themselves
-    // carry ~1e-2 relative error, the native exponential's 1e-6 is irrelevant here).
-    __shared__ Partial scratch[4];
+  static constexpr bool kReducesPartial = true;
+  // Per-lane partial of one 64 x 64 wave tile.  Two passes over the 64 accumulators of this lane: the maximum of its
+  // negatives first, then one hardware exponential (v_exp_f32) per negative -- no data-dependent rescale branch (bf16
+  // mode: the scores themselves carry ~1e-2 relative error, the native exponential's 1e-6 is irrelevant here).
+  __device__ __forceinline__ Partial lane_partial(f32x16 (&acc)[2][2], int64_t mb, int64_t nb, int64_t M,
+                                                  int64_t N) const {
     const int lane = threadIdx.x & 63;
     const int col_l = lane & 31, half = lane >> 5;
     float mx = MI_NEG_INF, pos = 0.0f;
     unsigned cnt = 0;
+    if (!scores && mb + 64 <= M && nb + 64 <= N) {
+      // interior tile, no score output: branch-free.  A pair is a negative iff the study ids differ (the diagonal
+      // pairs a sample with itself, so it never counts as one); the diagonal needs a look only where the tile's row
+      // and column ranges meet.
+      const int64_t dlo = row_offset + mb - nb;  // global row - column of the tile's (0, 0)
+      const bool has_diag = dlo > -64 && dlo < 64;
 #pragma unroll
-    for (int tm = 0; tm < 2; ++tm)
+      for (int tm = 0; tm < 2; ++tm) {
+        int64_t sr[16];
 #pragma unroll
-      for (int tn = 0; tn < 2; ++tn) {
-        const int64_t col = nb + tn * 32 + col_l;
-        const int64_t sc = col < N ? sid_cols[col] : 0;
+        for (int r = 0; r < 16; ++r) sr[r] = sid_rows[mb + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int64_t row = mb + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-          float v = acc[tm][tn][r];
-          int kind = 0;
-          if (row < M && col < N) {
-            if (scores) scores[row * N + col] = v;
-            kind = pair_kind(row_offset + row, col, sid_rows[row], sc);
+        for (int tn = 0; tn < 2; ++tn) {
+          const int64_t sc = sid_cols[nb + tn * 32 + col_l];
+          // the element is on the diagonal iff its row offset inside the 32-row group equals d
+          const int d = has_diag ? (int)(tn * 32 + col_l - tm * 32 - 4 * half - dlo) : -1;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float v = acc[tm][tn][r];
+            const bool neg = sr[r] != sc;
+            if (has_diag) pos += (d == (r & 3) + 8 * (r >> 2)) ? v : 0.0f;
+            const float vn = neg ? v : MI_NEG_INF;
+            mx = fmaxf(mx, vn);
+            cnt += neg ? 1u : 0u;
+            acc[tm][tn][r] = vn;
           }
-          if (kind == 1) pos += v;
-          if (kind == 2) {
-            mx = fmaxf(mx, v);
-            cnt += 1;
-          } else {
-            v = MI_NEG_INF;  // contributes exp(-inf) = 0 below
-          }
-          acc[tm][tn][r] = v;
         }
       }
+    } else {
+#pragma unroll
+      for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn) {
+          const int64_t col = nb + tn * 32 + col_l;
+          const int64_t sc = col < N ? sid_cols[col] : 0;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int64_t row = mb + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            float v = acc[tm][tn][r];
+            int kind = 0;
+            if (row < M && col < N) {
+              if (scores) scores[row * N + col] = v;
+              kind = pair_kind(row_offset + row, col, sid_rows[row], sc);
+            }
+            if (kind == 1) pos += v;
+            if (kind == 2) {
+              mx = fmaxf(mx, v);
+              cnt += 1;
+            } else {
+              v = MI_NEG_INF;  // contributes exp(-inf) = 0 below
+            }
+            acc[tm][tn][r] = v;
+          }
+        }
+    }
     float s = 0.0f;
     if (cnt > 0) {
 #pragma unroll
@@ -164,7 +264,12 @@ struct EpiScoreLse2 {
 #pragma unroll
           for (int r = 0; r < 16; ++r) s += __expf(acc[tm][tn][r] - mx);
     }
-    Partial p{mx, s, pos, cnt};
+    return Partial{mx, s, pos, cnt};
+  }
+  __device__ __forceinline__ void operator()(f32x16 (&acc)[2][2], int64_t mb, int64_t nb, int64_t M, int64_t N, int,
+                                             int, char*) const {
+    __shared__ Partial scratch[4];
+    Partial p = lane_partial(acc, mb, nb, M, N);
     p = block_reduce_partial<4>(p, scratch);
     if (threadIdx.x == 0) partials[(int64_t)blockIdx.y * gridDim.x + blockIdx.x] = p;
   }
@@ -172,6 +277,7 @@ struct EpiScoreLse2 {
 
 // G = grad_out * dL/dS as bf16, row-major [M][N] and transposed [N][M]
 struct EpiGradScore2 {
+  static constexpr bool kReducesPartial = false;
   const int64_t* sid_rows;
   const int64_t* sid_cols;
   int64_t row_offset;
@@ -180,35 +286,64 @@ struct EpiGradScore2 {
   bf16_t* g;
   bf16_t* gt;
   __device__ __forceinline__ void operator()(f32x16 (&acc)[2][2], int64_t mb, int64_t nb, int64_t M, int64_t N, int,
-                                             int) const {
+                                             int, char* lds) const {
     const float go = grad_out ? grad_out[0] : 1.0f;
     const float lse = stats->lse;
     const float gpos = -go / (float)stats->n_pos;
     // overwrite the accumulators with G, then store both orientations
     const int lane = threadIdx.x & 63;
     const int col_l = lane & 31, half = lane >> 5;
+    const bool staged = (M % 8 == 0) && (N % 8 == 0);
+    if (staged && mb + 64 <= M && nb + 64 <= N) {
+      // interior tile: branch-free (see EpiScoreLse2::lane_partial)
+      const int64_t dlo = row_offset + mb - nb;
+      const bool has_diag = dlo > -64 && dlo < 64;
 #pragma unroll
-    for (int tm = 0; tm < 2; ++tm)
+      for (int tm = 0; tm < 2; ++tm) {
+        int64_t sr[16];
 #pragma unroll
-      for (int tn = 0; tn < 2; ++tn) {
-        const int64_t col = nb + tn * 32 + col_l;
-        const int64_t sc = col < N ? sid_cols[col] : 0;
+        for (int r = 0; r < 16; ++r) sr[r] = sid_rows[mb + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int64_t row = mb + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-          float gv = 0.0f;
-          if (row < M && col < N) {
-            const int kind = pair_kind(row_offset + row, col, sid_rows[row], sc);
-            if (kind == 1) gv = gpos;
-            else if (kind == 2) gv = go * __expf(acc[tm][tn][r] - lse);  // bf16 output: native exp is ample
-            g[row * N + col] = (bf16_t)gv;
+        for (int tn = 0; tn < 2; ++tn) {
+          const int64_t sc = sid_cols[nb + tn * 32 + col_l];
+          const int d = has_diag ? (int)(tn * 32 + col_l - tm * 32 - 4 * half - dlo) : -1;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float e = go * __expf(acc[tm][tn][r] - lse);  // bf16 output: native exp is ample
+            float gv = sr[r] != sc ? e : 0.0f;
+            if (has_diag) gv = (d == (r & 3) + 8 * (r >> 2)) ? gpos : gv;
+            acc[tm][tn][r] = gv;
           }
-          acc[tm][tn][r] = gv;
         }
       }
-    foreach_acc4(acc, mb, nb, [&](int64_t row0, int64_t col, float v0, float v1, float v2, float v3) {
-      if (col < N) store4_transposed(gt, M, row0, col, M, v0, v1, v2, v3);
-    });
+    } else {
+#pragma unroll
+      for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn) {
+          const int64_t col = nb + tn * 32 + col_l;
+          const int64_t sc = col < N ? sid_cols[col] : 0;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int64_t row = mb + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            float gv = 0.0f;
+            if (row < M && col < N) {
+              const int kind = pair_kind(row_offset + row, col, sid_rows[row], sc);
+              if (kind == 1) gv = gpos;
+              else if (kind == 2) gv = go * __expf(acc[tm][tn][r] - lse);
+              if (!staged) g[row * N + col] = (bf16_t)gv;
+            }
+            acc[tm][tn][r] = gv;
+          }
+        }
+    }
+    if (staged) {
+      wave_tile_store_bf16(acc, lds, g, N, gt, M, mb, nb, M, N);
+    } else {
+      foreach_acc4(acc, mb, nb, [&](int64_t row0, int64_t col, float v0, float v1, float v2, float v3) {
+        if (col < N) store4_transposed(gt, M, row0, col, M, v0, v1, v2, v3);
+      });
+    }
   }
 };
 
@@ -293,7 +428,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmBf16Args args, Ep
     if (more) store_tile(buf ^ 1);
     __syncthreads();
   }
-  epi(acc, m0 + wm * 64, n0 + wn * 64, P.m, P.n, prob, zsplit);
+  epi(acc, m0 + wm * 64, n0 + wn * 64, P.m, P.n, prob, zsplit, smem_raw + wave * kEpiLdsPerWave);
 }
 
 
@@ -394,7 +529,132 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_glds_kernel(GemmBf16Args arg
     }
     __syncthreads();  // hipcc waits vmcnt(0) before the barrier: tile t+1 has landed, buffer `buf` is free
   }
-  epi(acc, m0 + wm * 64, n0 + wn * 64, P.m, P.n, prob, zsplit);
+  epi(acc, m0 + wm * 64, n0 + wn * 64, P.m, P.n, prob, zsplit, smem_raw + wave * kEpiLdsPerWave);
+}
+
+// ------------------------------------------------------------------------------------------------ 256 x 256 tiles
+// The K = d (512) GEMMs over the B x B score matrix (score+LSE, G) are bound by LDS ingest per CU, not by MFMA issue:
+// a 128 x 128 tile moves 32 KB per 64-deep K step for 2 MFLOP.  A 256 x 256 tile doubles the flops per ingested byte
+// and reads 6 fragments per 8 MFMAs instead of 4 per 4.  512 threads = 8 waves (2 x 4), each 128 x 64 = 4 x 2 MFMA
+// tiles (128 accumulator registers); same LDS-DMA + XOR swizzle as above; 2 x 64 KB of LDS, one workgroup per CU, so a
+// 4096 x 4096 problem is exactly one workgroup per CU.  Single problem, no split-K.
+template <class Epi>
+__global__ __launch_bounds__(512, 1) void gemm_bf16_big_kernel(GemmBf16Args args, Epi epi) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  // [buf][A | B][256 rows][128 bytes]
+  const GemmBf16Problem& P = args.p[0];
+  int bx_, by_;
+  xcd_tile(bx_, by_);
+  const int64_t m0 = (int64_t)by_ * 256, n0 = (int64_t)bx_ * 256;
+  if (m0 >= P.m || n0 >= P.n) return;
+
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int wm = wave >> 2, wn = wave & 3;
+  const int r32 = lane & 31, half = lane >> 5;
+
+  const char* asrc[4];
+  const char* bsrc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = 32 * wave + 8 * i + (lane >> 3);
+    const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+    int64_t am = m0 + row, bn = n0 + row;
+    if (am >= P.m) am = P.m - 1;
+    if (bn >= P.n) bn = P.n - 1;
+    asrc[i] = reinterpret_cast<const char*>(P.a + am * P.lda) + chunk * 16;
+    bsrc[i] = reinterpret_cast<const char*>(P.b + bn * P.ldb) + chunk * 16;
+  }
+  auto issue_tile = [&](int64_t t, int buf) {
+    char* abase = smem_raw + buf * 65536 + (32 * wave) * 128;
+    char* bbase = abase + 32768;
+    const int64_t koff = t * (kG2KT * 2);  // bytes
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(asrc[i] + koff),
+                                       (__attribute__((address_space(3))) void*)(abase + i * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bsrc[i] + koff),
+                                       (__attribute__((address_space(3))) void*)(bbase + i * 1024), 16, 0, 0);
+    }
+  };
+
+  f32x16 acc[2][2][2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[h][a][b][r] = 0.0f;
+
+  int aoff[4], boff[2], aswz[4], bswz[2];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int ar = wm * 128 + t * 32 + r32;
+    aoff[t] = ar * 128;
+    aswz[t] = (ar >> 1) & 7;
+  }
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int br_ = wn * 64 + t * 32 + r32;
+    boff[t] = br_ * 128;
+    bswz[t] = (br_ >> 1) & 7;
+  }
+
+  const int64_t nt = P.k / kG2KT;
+  if (nt > 0) issue_tile(0, 0);
+  __syncthreads();
+  for (int64_t t = 0; t < nt; ++t) {
+    const int buf = (int)(t & 1);
+    if (t + 1 < nt) issue_tile(t + 1, buf ^ 1);
+    const char* at = smem_raw + buf * 65536;
+    const char* bt = at + 32768;
+#pragma unroll
+    for (int kk = 0; kk < kG2KT / 16; ++kk) {
+      bf16x8 af[4], bfr[2];
+#pragma unroll
+      for (int tm = 0; tm < 4; ++tm)
+        af[tm] = *reinterpret_cast<const bf16x8*>(at + aoff[tm] + 16 * ((2 * kk + half) ^ aswz[tm]));
+#pragma unroll
+      for (int tn = 0; tn < 2; ++tn)
+        bfr[tn] = *reinterpret_cast<const bf16x8*>(bt + boff[tn] + 16 * ((2 * kk + half) ^ bswz[tn]));
+#pragma unroll
+      for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn)
+          acc[tm >> 1][tm & 1][tn] =
+              __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[tm], bfr[tn], acc[tm >> 1][tm & 1][tn], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  const int64_t mb = m0 + wm * 128, nb = n0 + wn * 64;
+  if constexpr (Epi::kReducesPartial) {
+    __shared__ Partial scratch[8];
+    Partial p = epi.lane_partial(acc[0], mb, nb, P.m, P.n);
+    const Partial q = epi.lane_partial(acc[1], mb + 64, nb, P.m, P.n);
+    lse_merge(p.m, p.s, q.m, q.s);
+    p.pos += q.pos;
+    p.cnt += q.cnt;
+    p = block_reduce_partial<8>(p, scratch);
+    if (threadIdx.x == 0) epi.partials[(int64_t)blockIdx.y * gridDim.x + blockIdx.x] = p;
+  } else {
+    char* lds = smem_raw + wave * kEpiLdsPerWave;
+    epi(acc[0], mb, nb, P.m, P.n, 0, 0, lds);
+    epi(acc[1], mb + 64, nb, P.m, P.n, 0, 0, lds);
+  }
+}
+
+constexpr size_t kG2SmemBig = 2 * 2 * 32768;  // 131,072 bytes
+
+// number of workgroup partials a reducing epilogue writes for an M x N problem (the launcher picks the tile size)
+static inline bool gemm_bf16_use_big(int64_t m, int64_t n, int64_t k) {
+  static const bool off = getenv("MI_GEMM_NO_BIG") != nullptr;
+  return !off && k % kG2KT == 0 && k > 0 && ((m + 255) / 256) * ((n + 255) / 256) >= 192;
+}
+static inline int64_t gemm_bf16_n_partials(int64_t m, int64_t n, int64_t k) {
+  const int64_t t = gemm_bf16_use_big(m, n, k) ? 256 : kTile;
+  return ((m + t - 1) / t) * ((n + t - 1) / t);
 }
 
 constexpr size_t kG2SmemGlds = 2 * 2 * 16384;  // 65,536 bytes
@@ -421,6 +681,22 @@ static inline int launch_gemm_bf16(const GemmBf16Args& args, int n_splits, const
   }
   bool dma_ok = args.k_chunk % kG2KT == 0 || n_splits == 1;
   for (int q = 0; q < args.n_problems; ++q) dma_ok = dma_ok && args.p[q].k % kG2KT == 0 && args.p[q].k > 0;
+  if (dma_ok && args.n_problems == 1 && n_splits == 1 && gemm_bf16_use_big(mm, nn, args.p[0].k)) {
+    static bool big_attr_set = false;  // per Epi instantiation
+    if (!big_attr_set) {
+      hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_big_kernel<Epi>,
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)kG2SmemBig);
+      if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(gemm_bf16_big_kernel)");
+      big_attr_set = true;
+    }
+    dim3 grid((unsigned)((nn + 255) / 256), (unsigned)((mm + 255) / 256), 1);
+    {
+      ProfScope prof_(what, st);
+      hipLaunchKernelGGL((gemm_bf16_big_kernel<Epi>), grid, dim3(512), kG2SmemBig, st, args, epi);
+    }
+    MI_LAUNCH_CHECK(what);
+    return MI_OK;
+  }
   dim3 grid((unsigned)((nn + kTile - 1) / kTile), (unsigned)((mm + kTile - 1) / kTile),
             (unsigned)(args.n_problems * n_splits));
   {

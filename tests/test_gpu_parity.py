@@ -266,6 +266,37 @@ def test_bilinear_full_size_properties(dev):
     assert torch.isfinite(xl.grad).all() and torch.isfinite(critic.weight.grad).all()
 
 
+def test_bilinear_full_size_vs_oracle(dev):
+    """B=4096, d=512, bf16 with duplicated study ids against the oracle (the 256 x 256-tile score / G kernels are only
+    selected at this size).  Loss against the oracle that rounds at the same points; gradients against the exact one."""
+    from mutual_info_img_txt import mi_critics
+    from mutual_info_img_txt.model import BilinearCritic
+    b, d = 4096, 512
+    gen = torch.Generator().manual_seed(11)
+    x = torch.randn(b, d, generator=gen)
+    y = torch.randn(b, d, generator=gen)
+    w = torch.randn(d, d, generator=gen) * (0.3 / d ** 0.5)
+    sid = torch.randint(0, b // 2, (b,), generator=gen)   # plenty of dropped pairs, on and off the diagonal tiles
+    critic = BilinearCritic(d, d)
+    with torch.no_grad():
+        critic.weight.copy_(w)
+    critic.to(dev)
+    xl, yl = x.to(dev).requires_grad_(True), y.to(dev).requires_grad_(True)
+    loss, stats = mi_critics.fused_mi_bound(xl, yl, sid.to(dev), critic, "infonce", precision="bf16", return_stats=True)
+    loss.sum().backward()
+    from mutual_info_img_txt import _hip
+    s_r = orc.bilinear_scores(x.double(), y.double(), w.double(), round_fn=orc.round_bf16)
+    mask = orc.negative_mask(sid)
+    assert _hip.stats_dict(stats)["n_neg"] == int(mask.sum())
+    sc = float(s_r.abs().max())
+    ref_loss = orc.bound_from_matrix(s_r, sid, "infonce")
+    assert abs(float(loss) - float(ref_loss)) < 2e-3 * max(sc, 1.0)
+    o = orc.matrix_step(lambda a, c, ww: orc.bilinear_scores(a, c, ww), [x.double(), y.double(), w.double()], sid, "infonce")
+    for got, ref in zip((xl.grad, yl.grad, critic.weight.grad), o["grads"]):
+        err = float((got.cpu().double() - ref).abs().max()) / float(ref.abs().max())
+        assert err < 6e-2, err
+
+
 # ------------------------------------------------------------------------------------------------ fused concat-MLP
 def _mlp_on(dev, d_in, hidden, params):
     from mutual_info_img_txt.model import make_mlp
