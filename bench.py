@@ -42,9 +42,11 @@ def parse_args():
     p.add_argument("--critic", default="bilinear", choices=["bilinear", "concat_mlp"])
     p.add_argument("--estimator", default="infonce", choices=["dv", "infonce"])
     p.add_argument("--precision", default="bf16", choices=["bf16", "f32"])
-    p.add_argument("--graph", default="off", choices=["auto", "on", "off"],
-                   help="replay the step from a hipGraph (off by default: capture of the ctypes-launched sequence "
-                        "currently crashes inside capture_end on ROCm 7.2 and cannot be caught from Python)")
+    p.add_argument("--graph", default="auto", choices=["auto", "on", "off"],
+                   help="replay the step from a hipGraph.  auto: single-GPU bilinear step only (eagerly that step is "
+                        "bound by the host's launch rate, not by the GPU); the concat-MLP step (52 ms of kernels) and "
+                        "multi-GPU runs stay eager -- capturing the concat sequence crashes inside capture_end on "
+                        "ROCm 7.2, which cannot be caught from Python")
     p.add_argument("--no-secondary", action="store_true")
     p.add_argument("--secondary-steps", type=int, default=5)
     p.add_argument("--no-cpu-baseline", action="store_true")
@@ -94,6 +96,8 @@ def algorithmic_flops(kind, b, d_img, d_txt, h1=1024, h2=512):
 def kernel_flops(name, br, b, d_img, d_txt, h1=1024, h2=512):
     """Algorithmic flops of ONE launch of a named kernel (0 for HBM-bound helper kernels)."""
     if name.startswith("bilinear"):
+        if "dW" in name and "|" in name:  # two-problem launch: dW = X^T dT and dX = dT W^T
+            return 4.0 * br * d_img * d_txt
         if "|" in name:  # two-problem launch: dT = G Y and dY = G^T T
             return 4.0 * br * b * d_txt
         if any(t in name for t in ("score+LSE", "bilinear G", "dT = G Y", "dY = G^T T")):
@@ -144,6 +148,7 @@ class Stepper:
     def try_capture(self):
         self.eager()
         torch.cuda.synchronize()
+        self.loss = None
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
@@ -151,6 +156,9 @@ class Stepper:
                 self.eager()
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
+        # drop the last autograd graph: its AccumulateGrad nodes are bound to the warm-up stream, and a backward that
+        # reuses them inside the capture synchronises with that (non-capturing) stream and takes the process down
+        self.loss = None
         self.x.grad = None
         self.y.grad = None
         for p in self.critic.parameters():
@@ -277,7 +285,8 @@ def main():
     def run(kind, steps, warmup):
         st = Stepper(kind, args, rank, world, device, group)
         graph_used = False
-        if args.graph != "off":
+        want_graph = args.graph == "on" or (args.graph == "auto" and kind == "bilinear" and world == 1)
+        if want_graph:
             try:
                 st.try_capture()
                 graph_used = True

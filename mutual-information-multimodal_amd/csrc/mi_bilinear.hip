@@ -129,22 +129,30 @@ static int bilinear_bwd_fast(const int64_t* sid_rows, const int64_t* sid_cols, i
   e2.out[1] = EpiOut{grad_y, dy, 0, nullptr, 0, nullptr, 0};
   rc = launch_gemm_bf16(two, 1, e2, st, "bilinear dT = G Y | dY = G^T T");
   if (rc) return rc;
-  // dW[a, c] = sum_i X[i, a] dT[i, c]: A = X^T [dx][br], B = dT^T [dy][br], split over i
+  // dW[a, c] = sum_i X[i, a] dT[i, c]: A = X^T [dx][br], B = dT^T [dy][br], split over i into slabs
+  // dX[i, a] = sum_c dT[i, c] W[a, c]: A = dT [br][dy], B = W [dx][dy]
+  // Both only wait for dT: one launch (few tiles each; on their own they leave most CUs idle).
+  GemmBf16Args dwx{};
+  dwx.p[0] = GemmBf16Problem{p.xtb, br, p.dttb, br, dx, dy, br};
+  dwx.p[1] = GemmBf16Problem{p.dtb, dy, p.wb, dy, br, dx, dy};
+  dwx.n_problems = 2;
   EpiStoreMulti e3{};
   e3.out[0] = EpiOut{p.dw_slab, dy, dx * dy, nullptr, 0, nullptr, 0};
-  rc = launch_gemm_bf16(one_problem(p.xtb, br, p.dttb, br, dx, dy, br, p.dw_kchunk), p.dw_splits, e3, st,
-                        "bilinear dW = X^T dT");
-  if (rc) return rc;
-  {
-    ProfScope prof_("slab_reduce_ld_kernel", st);
-    hipLaunchKernelGGL(slab_reduce_ld_kernel, dim3(256), dim3(256), 0, st, (const float*)p.dw_slab, p.dw_splits, dx, dy,
-                       grad_w, dy);
+  e3.out[1] = EpiOut{grad_x, dx, 0, nullptr, 0, nullptr, 0};
+  const int splits[2] = {p.dw_splits, 1};
+  const int64_t chunks[2] = {p.dw_kchunk, dy};
+  rc = launch_gemm_bf16_flat(dwx, splits, chunks, e3, st, "bilinear dW = X^T dT | dX = dT W^T");
+  if (rc == MI_EINVAL) {  // shapes the LDS-DMA kernel does not take: one launch each
+    EpiStoreMulti e4{};
+    e4.out[0] = e3.out[0];
+    rc = launch_gemm_bf16(one_problem(p.xtb, br, p.dttb, br, dx, dy, br, p.dw_kchunk), p.dw_splits, e4, st,
+                          "bilinear dW = X^T dT");
+    if (rc) return rc;
+    e4.out[0] = e3.out[1];
+    rc = launch_gemm_bf16(one_problem(p.dtb, dy, p.wb, dy, br, dx, dy), 1, e4, st, "bilinear dX = dT W^T");
   }
-  MI_LAUNCH_CHECK("slab_reduce_ld_kernel");
-  // dX[i, a] = sum_c dT[i, c] W[a, c]: A = dT [br][dy], B = W [dx][dy]
-  EpiStoreMulti e4{};
-  e4.out[0] = EpiOut{grad_x, dx, 0, nullptr, 0, nullptr, 0};
-  return launch_gemm_bf16(one_problem(p.dtb, dy, p.wb, dy, br, dx, dy), 1, e4, st, "bilinear dX = dT W^T");
+  if (rc) return rc;
+  return launch_slab_reduce_ld(p.dw_slab, p.dw_splits, dx, dy, grad_w, dy, st, "slab_reduce_ld_kernel");
 }
 
 // ------------------------------------------------------------------------------------------------ generic path

@@ -45,16 +45,16 @@ static hipEvent_t prof_event() {
     return e;
   }
   hipEvent_t e;
-  hipEventCreate(&e);
+  (void)hipEventCreate(&e);
   return e;
 }
 void profile_push(const char* name, hipStream_t st, bool begin) {
   if (begin) {
     ProfEntry e{name, prof_event(), prof_event()};
-    hipEventRecord(e.a, st);
+    (void)hipEventRecord(e.a, st);
     g_prof.push_back(e);
   } else {
-    hipEventRecord(g_prof.back().b, st);
+    (void)hipEventRecord(g_prof.back().b, st);
   }
 }
 
@@ -308,7 +308,7 @@ int mi_profile_end(char* names, size_t names_bytes, float* ms, int capacity, int
     const size_t len = strlen(e.name) + 1;
     if (off + len > names_bytes) break;
     float t = 0.0f;
-    hipEventElapsedTime(&t, e.a, e.b);
+    (void)hipEventElapsedTime(&t, e.a, e.b);
     ms[n] = t;
     memcpy(names + off, e.name, len);  // NUL-separated list
     off += len;

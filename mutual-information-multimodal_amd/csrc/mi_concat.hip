@@ -261,24 +261,16 @@ static int concat_bwd_impl(const float* x, const float* y, const float* w1, cons
     rc = launch_gemm<float>(make_operand((const float*)p.du, 1, h1), make_operand(x, 1, dx), h1, dx, br, e, st,
                             "concat dW1x = dU^T X", sx, p.w1_kchunk_x);
     if (rc) return rc;
-    {
-      ProfScope prof_("slab_reduce_ld_kernel", st);
-      hipLaunchKernelGGL(slab_reduce_ld_kernel, dim3(512), dim3(256), 0, st, (const float*)p.w1_slab, sx, (int64_t)h1, dx,
-                         grad_w1, d);
-    }
-    MI_LAUNCH_CHECK("slab_reduce_ld_kernel");
+    rc = launch_slab_reduce_ld(p.w1_slab, sx, h1, dx, grad_w1, d, st, "slab_reduce_ld_kernel");
+    if (rc) return rc;
     EpiStore e2{p.w1_slab, dy, nullptr, 1.0f, 0};
     e2.slab_stride = (int64_t)h1 * dy;
     const int sy = (int)((b + p.w1_kchunk_y - 1) / p.w1_kchunk_y);
     rc = launch_gemm<float>(make_operand((const float*)p.dv, 1, h1), make_operand(y, 1, dy), h1, dy, b, e2, st,
                             "concat dW1y = dV^T Y", sy, p.w1_kchunk_y);
     if (rc) return rc;
-    {
-      ProfScope prof_("slab_reduce_ld_kernel", st);
-      hipLaunchKernelGGL(slab_reduce_ld_kernel, dim3(512), dim3(256), 0, st, (const float*)p.w1_slab, sy, (int64_t)h1, dy,
-                         grad_w1 + dx, d);
-    }
-    MI_LAUNCH_CHECK("slab_reduce_ld_kernel");
+    rc = launch_slab_reduce_ld(p.w1_slab, sy, h1, dy, grad_w1 + dx, d, st, "slab_reduce_ld_kernel");
+    if (rc) return rc;
   }
   {
     ProfScope prof_("colsum_kernel", st);

@@ -21,9 +21,7 @@ constexpr int kG2LD = 72;   // LDS row pitch in bf16 elements
 // fetches the panel again (measured on dT = G Y: 286 MB fetched per launch against 75 MB of operands).  Remap the
 // linear id so that, inside each group of 8 row-panels, panel p runs all its column tiles on XCD p % 8.  Bijective for
 // any grid; affects speed only.
-__device__ __forceinline__ void xcd_tile(int& bx, int& by) {
-  const int nx = (int)gridDim.x, ny = (int)gridDim.y;
-  const int L = (int)blockIdx.x + nx * (int)blockIdx.y;
+__device__ __forceinline__ void xcd_tile_lin(int L, int nx, int ny, int& bx, int& by) {
   const int full = ny / 8;
   if (L < full * 8 * nx) {
     const int g = L / (8 * nx), r = L - g * 8 * nx;
@@ -35,6 +33,42 @@ __device__ __forceinline__ void xcd_tile(int& bx, int& by) {
     bx = r - (r / nx) * nx;
   }
 }
+__device__ __forceinline__ void xcd_tile(int& bx, int& by) {
+  xcd_tile_lin((int)blockIdx.x + (int)gridDim.x * (int)blockIdx.y, (int)gridDim.x, (int)gridDim.y, bx, by);
+}
+
+// Short-K problems over a large M x N grid (score / G: K = d): the row-panel order above makes every XCD stream all of
+// B (N x K, larger than its 4 MB L2), and the tiles are then fed from the Infinity Cache at about half the L2 rate.
+// Cut the tile grid into gy x gx = 8 rectangular blocks, one per XCD, so that the rows of A and B one XCD touches
+// ((M / gy + N / gx) * K * 2 bytes) stay L2-resident.  Needs gridDim.y % gy == 0 and gridDim.x % gx == 0.
+__device__ __forceinline__ void xcd_block_tile(int gy, int gx, int& bx, int& by) {
+  const int nx = (int)gridDim.x, ny = (int)gridDim.y;
+  const int L = (int)blockIdx.x + nx * (int)blockIdx.y;
+  const int x = L & 7, s = L >> 3;
+  const int ty = ny / gy, tx = nx / gx;
+  by = (x / gx) * ty + s / tx;
+  bx = (x % gx) * tx + s % tx;
+}
+
+// launcher side: pick the block grid for an (ny x nx)-tile problem, or 0 x 0 for the row-panel order
+static inline void xcd_pick_blocks(int64_t ny, int64_t nx, int64_t tile, int64_t k, int nz, int& gy, int& gx) {
+  gy = gx = 0;
+  static const bool off = getenv("MI_GEMM_NO_XCD_BLOCKS") != nullptr;  // A/B switch
+  if (off || nz != 1) return;
+  const int64_t l2 = 3 << 20;  // leave some of the 4 MB for the output stream
+  if (nx * tile * k * 2 + 8 * tile * k * 2 <= l2) return;  // all of B plus a few A panels fit anyway
+  int64_t best = -1;
+  const int cand[4][2] = {{2, 4}, {4, 2}, {1, 8}, {8, 1}};
+  for (auto& c : cand) {
+    if (ny % c[0] || nx % c[1]) continue;
+    const int64_t bytes = (ny / c[0] + nx / c[1]) * tile * k * 2;
+    if (best < 0 || bytes < best) {
+      best = bytes;
+      gy = c[0];
+      gx = c[1];
+    }
+  }
+}
 
 struct GemmBf16Problem {
   const bf16_t* a;
@@ -42,12 +76,17 @@ struct GemmBf16Problem {
   const bf16_t* b;
   int64_t ldb;
   int64_t m, n, k;
+  // flat launches only (launch_gemm_bf16_flat): own split-K chunk and the problem's range of workgroup ids
+  int64_t k_chunk;
+  int wg_begin, nx, ny;
 };
 
 struct GemmBf16Args {
   GemmBf16Problem p[2];
   int n_problems;   // 1 or 2
   int64_t k_chunk;  // split-K chunk (multiple of 64) when n_problems == 1 and gridDim.z > 1; else >= k
+  int flat;            // 1: 1-D grid, problem / split / tile decoded from blockIdx.x (set by launch_gemm_bf16_flat)
+  int xcd_gy, xcd_gx;  // set by the launcher: 8 = xcd_gy * xcd_gx blocks of the tile grid, one per XCD (0: row panels)
 };
 
 // Generic multi-output store epilogue (one set of outputs per problem): out = alpha * acc
@@ -357,7 +396,8 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmBf16Args args, Ep
   const int zsplit = (int)blockIdx.z / args.n_problems;
   const GemmBf16Problem& P = args.p[prob];
   int bx_, by_;
-  xcd_tile(bx_, by_);
+  if (args.xcd_gy) xcd_block_tile(args.xcd_gy, args.xcd_gx, bx_, by_);
+  else xcd_tile(bx_, by_);
   const int64_t m0 = (int64_t)by_ * kTile, n0 = (int64_t)bx_ * kTile;
   if (m0 >= P.m || n0 >= P.n) return;  // the grid covers the larger of two problems
   const int64_t kbeg = (int64_t)zsplit * args.k_chunk;
@@ -439,19 +479,35 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmBf16Args args, Ep
 //   chunk c (16 bytes = 8 k) of row r lives at LDS chunk position c ^ ((r >> 1) & 7).
 // Requires K (and the split-K chunk) to be multiples of 64; rows beyond M / N are clamped (they only feed outputs that
 // the epilogue discards).  64 KB of LDS -> 2 workgroups per CU.
+//
+// Flat launches (args.flat): a 1-D grid over two problems of different shape and split count (dX = dT W^T, one pass over
+// K = d, next to dW = X^T dT, split 16 ways over K = B); each problem owns a contiguous range of workgroup ids.
 template <class Epi>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_glds_kernel(GemmBf16Args args, Epi epi) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   // [buf][A | B][128 rows][128 bytes]
-  const int prob = (int)blockIdx.z % args.n_problems;
-  const int zsplit = (int)blockIdx.z / args.n_problems;
+  int prob, zsplit, bx_, by_;
+  int64_t k_chunk = args.k_chunk;
+  if (args.flat) {
+    const int L = (int)blockIdx.x;
+    prob = (args.n_problems == 2 && L >= args.p[1].wg_begin) ? 1 : 0;
+    const GemmBf16Problem& Q = args.p[prob];
+    const int local = L - Q.wg_begin, tiles = Q.nx * Q.ny;
+    zsplit = local / tiles;
+    xcd_tile_lin(local - zsplit * tiles, Q.nx, Q.ny, bx_, by_);
+    k_chunk = Q.k_chunk;
+  } else {
+    prob = (int)blockIdx.z % args.n_problems;
+    zsplit = (int)blockIdx.z / args.n_problems;
+    if (args.xcd_gy) xcd_block_tile(args.xcd_gy, args.xcd_gx, bx_, by_);
+    else xcd_tile(bx_, by_);
+  }
   const GemmBf16Problem& P = args.p[prob];
-  int bx_, by_;
-  xcd_tile(bx_, by_);
   const int64_t m0 = (int64_t)by_ * kTile, n0 = (int64_t)bx_ * kTile;
   if (m0 >= P.m || n0 >= P.n) return;
-  const int64_t kbeg = (int64_t)zsplit * args.k_chunk;
-  int64_t kend = kbeg + args.k_chunk;
+  const int64_t kbeg = (int64_t)zsplit * k_chunk;
+  if (kbeg >= P.k) return;  // flat launches: padding ids between the problems' ranges
+  int64_t kend = kbeg + k_chunk;
   if (kend > P.k) kend = P.k;
 
   const int tid = threadIdx.x;
@@ -460,11 +516,12 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_glds_kernel(GemmBf16Args arg
   const int r32 = lane & 31, half = lane >> 5;
 
   // staging: wave w, instruction i (0..3): rows 32 w + 8 i + (lane >> 3), LDS chunk position lane & 7
-  const char* asrc[4];
-  const char* bsrc[4];
+  constexpr int NI = 4;
+  const char* asrc[NI];
+  const char* bsrc[NI];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int row = 32 * wave + 8 * i + (lane >> 3);
+  for (int i = 0; i < NI; ++i) {
+    const int row = 8 * NI * wave + 8 * i + (lane >> 3);
     const int chunk = (lane & 7) ^ ((row >> 1) & 7);
     int64_t am = m0 + row, bn = n0 + row;
     if (am >= P.m) am = P.m - 1;
@@ -473,11 +530,11 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_glds_kernel(GemmBf16Args arg
     bsrc[i] = reinterpret_cast<const char*>(P.b + bn * P.ldb + kbeg) + chunk * 16;
   }
   auto issue_tile = [&](int64_t t, int buf) {
-    char* abase = smem_raw + buf * 32768 + (32 * wave) * 128;
+    char* abase = smem_raw + buf * 32768 + (8 * NI * wave) * 128;
     char* bbase = abase + 16384;
     const int64_t koff = t * (kG2KT * 2);  // bytes
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NI; ++i) {
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(asrc[i] + koff),
                                        (__attribute__((address_space(3))) void*)(abase + i * 1024), 16, 0, 0);
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bsrc[i] + koff),
@@ -504,6 +561,8 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_glds_kernel(GemmBf16Args arg
     bswz[t] = (br_ >> 1) & 7;
   }
 
+  constexpr int KK = kG2KT / 16;  // 16-deep MFMA steps per K tile
+  constexpr int kk0 = 0;
   const int64_t nt = (kend - kbeg) / kG2KT;
   if (nt > 0) issue_tile(0, 0);
   __syncthreads();
@@ -512,20 +571,28 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_glds_kernel(GemmBf16Args arg
     if (t + 1 < nt) issue_tile(t + 1, buf ^ 1);
     const char* at = smem_raw + buf * 32768;
     const char* bt = at + 16384;
-#pragma unroll
-    for (int kk = 0; kk < kG2KT / 16; ++kk) {
-      bf16x8 af[2], bfr[2];
+    // fragments of step q + 1 are requested before the MFMAs of step q (one wave per SIMD has nothing else to cover
+    // the ds_read latency); the sched_barriers keep the compiler from sinking the reads back to their first use
+    bf16x8 af[2][2], bfr[2][2];
+    auto read_frags = [&](int kk, int slot) {
 #pragma unroll
       for (int tm = 0; tm < 2; ++tm)
-        af[tm] = *reinterpret_cast<const bf16x8*>(at + aoff[tm] + 16 * ((2 * kk + half) ^ aswz[tm]));
+        af[slot][tm] = *reinterpret_cast<const bf16x8*>(at + aoff[tm] + 16 * ((2 * kk + half) ^ aswz[tm]));
 #pragma unroll
       for (int tn = 0; tn < 2; ++tn)
-        bfr[tn] = *reinterpret_cast<const bf16x8*>(bt + boff[tn] + 16 * ((2 * kk + half) ^ bswz[tn]));
+        bfr[slot][tn] = *reinterpret_cast<const bf16x8*>(bt + boff[tn] + 16 * ((2 * kk + half) ^ bswz[tn]));
+    };
+    read_frags(kk0, 0);
+#pragma unroll
+    for (int q = 0; q < KK; ++q) {
+      if (q + 1 < KK) read_frags(kk0 + q + 1, (q + 1) & 1);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
         for (int tn = 0; tn < 2; ++tn)
-          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[tm], bfr[tn], acc[tm][tn], 0, 0, 0);
+          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[q & 1][tm], bfr[q & 1][tn], acc[tm][tn], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
     }
     __syncthreads();  // hipcc waits vmcnt(0) before the barrier: tile t+1 has landed, buffer `buf` is free
   }
@@ -544,7 +611,8 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_big_kernel(GemmBf16Args args
   // [buf][A | B][256 rows][128 bytes]
   const GemmBf16Problem& P = args.p[0];
   int bx_, by_;
-  xcd_tile(bx_, by_);
+  if (args.xcd_gy) xcd_block_tile(args.xcd_gy, args.xcd_gx, bx_, by_);
+  else xcd_tile(bx_, by_);
   const int64_t m0 = (int64_t)by_ * 256, n0 = (int64_t)bx_ * 256;
   if (m0 >= P.m || n0 >= P.n) return;
 
@@ -610,21 +678,27 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_big_kernel(GemmBf16Args args
     if (t + 1 < nt) issue_tile(t + 1, buf ^ 1);
     const char* at = smem_raw + buf * 65536;
     const char* bt = at + 32768;
-#pragma unroll
-    for (int kk = 0; kk < kG2KT / 16; ++kk) {
-      bf16x8 af[4], bfr[2];
+    bf16x8 af[2][4], bfr[2][2];
+    auto read_frags = [&](int kk, int slot) {
 #pragma unroll
       for (int tm = 0; tm < 4; ++tm)
-        af[tm] = *reinterpret_cast<const bf16x8*>(at + aoff[tm] + 16 * ((2 * kk + half) ^ aswz[tm]));
+        af[slot][tm] = *reinterpret_cast<const bf16x8*>(at + aoff[tm] + 16 * ((2 * kk + half) ^ aswz[tm]));
 #pragma unroll
       for (int tn = 0; tn < 2; ++tn)
-        bfr[tn] = *reinterpret_cast<const bf16x8*>(bt + boff[tn] + 16 * ((2 * kk + half) ^ bswz[tn]));
+        bfr[slot][tn] = *reinterpret_cast<const bf16x8*>(bt + boff[tn] + 16 * ((2 * kk + half) ^ bswz[tn]));
+    };
+    read_frags(0, 0);
+#pragma unroll
+    for (int kk = 0; kk < kG2KT / 16; ++kk) {
+      if (kk + 1 < kG2KT / 16) read_frags(kk + 1, (kk + 1) & 1);  // ahead of this step's MFMAs
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int tm = 0; tm < 4; ++tm)
 #pragma unroll
         for (int tn = 0; tn < 2; ++tn)
-          acc[tm >> 1][tm & 1][tn] =
-              __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[tm], bfr[tn], acc[tm >> 1][tm & 1][tn], 0, 0, 0);
+          acc[tm >> 1][tm & 1][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[kk & 1][tm], bfr[kk & 1][tn],
+                                                                             acc[tm >> 1][tm & 1][tn], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
     }
     __syncthreads();
   }
@@ -661,8 +735,11 @@ constexpr size_t kG2SmemGlds = 2 * 2 * 16384;  // 65,536 bytes
 constexpr size_t kG2Smem = 2 * 2 * kTile * kG2LD * sizeof(bf16_t);  // 73,728 bytes
 
 template <class Epi>
-static inline int launch_gemm_bf16(const GemmBf16Args& args, int n_splits, const Epi& epi, hipStream_t st,
+static inline int launch_gemm_bf16(const GemmBf16Args& args_in, int n_splits, const Epi& epi, hipStream_t st,
                                    const char* what) {
+  GemmBf16Args args = args_in;
+  args.flat = 0;
+  args.xcd_gy = args.xcd_gx = 0;
   int64_t mm = args.p[0].m, nn = args.p[0].n;
   if (args.n_problems == 2) {
     if (args.p[1].m > mm) mm = args.p[1].m;
@@ -690,6 +767,7 @@ static inline int launch_gemm_bf16(const GemmBf16Args& args, int n_splits, const
       big_attr_set = true;
     }
     dim3 grid((unsigned)((nn + 255) / 256), (unsigned)((mm + 255) / 256), 1);
+    xcd_pick_blocks(grid.y, grid.x, 256, args.p[0].k, 1, args.xcd_gy, args.xcd_gx);
     {
       ProfScope prof_(what, st);
       hipLaunchKernelGGL((gemm_bf16_big_kernel<Epi>), grid, dim3(512), kG2SmemBig, st, args, epi);
@@ -699,10 +777,48 @@ static inline int launch_gemm_bf16(const GemmBf16Args& args, int n_splits, const
   }
   dim3 grid((unsigned)((nn + kTile - 1) / kTile), (unsigned)((mm + kTile - 1) / kTile),
             (unsigned)(args.n_problems * n_splits));
+  xcd_pick_blocks(grid.y, grid.x, kTile, args.p[0].k, (int)grid.z, args.xcd_gy, args.xcd_gx);
   {
     ProfScope prof_(what, st);
     if (dma_ok) hipLaunchKernelGGL((gemm_bf16_glds_kernel<Epi>), grid, dim3(256), kG2SmemGlds, st, args, epi);
     else hipLaunchKernelGGL((gemm_bf16_kernel<Epi>), grid, dim3(256), kG2Smem, st, args, epi);
+  }
+  MI_LAUNCH_CHECK(what);
+  return MI_OK;
+}
+
+// Two problems with their own split counts in one launch (problem q: splits[q] K chunks of k_chunks[q], partial sums to
+// the epilogue's slabs).  Falls back to one launch per problem when a shape does not suit the LDS-DMA kernel.
+template <class Epi>
+static inline int launch_gemm_bf16_flat(const GemmBf16Args& args_in, const int (&splits)[2], const int64_t (&k_chunks)[2],
+                                        const Epi& epi, hipStream_t st, const char* what) {
+  GemmBf16Args args = args_in;
+  bool ok = args.n_problems == 2;
+  int total = 0;
+  for (int q = 0; q < 2 && ok; ++q) {
+    GemmBf16Problem& P = args.p[q];
+    ok = P.m > 0 && P.n > 0 && P.k > 0 && P.k % kG2KT == 0 && (splits[q] == 1 || k_chunks[q] % kG2KT == 0);
+    P.k_chunk = splits[q] == 1 ? P.k : k_chunks[q];
+    P.nx = (int)((P.n + kTile - 1) / kTile);
+    P.ny = (int)((P.m + kTile - 1) / kTile);
+    P.wg_begin = total;
+    total += P.nx * P.ny * splits[q];
+    total = (total + 7) / 8 * 8;  // keep every problem's first workgroup on XCD 0 (ids in the gap return at once)
+  }
+  if (!ok) return MI_EINVAL;
+  static bool attr_set = false;  // per Epi instantiation
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_glds_kernel<Epi>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)kG2SmemGlds);
+    if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(gemm_bf16_glds_kernel)");
+    attr_set = true;
+  }
+  args.flat = 1;
+  args.xcd_gy = args.xcd_gx = 0;
+  args.k_chunk = 0;
+  {
+    ProfScope prof_(what, st);
+    hipLaunchKernelGGL((gemm_bf16_glds_kernel<Epi>), dim3((unsigned)total), dim3(256), kG2SmemGlds, st, args, epi);
   }
   MI_LAUNCH_CHECK(what);
   return MI_OK;
@@ -788,16 +904,54 @@ static inline int launch_cvt_transpose3(const CvtJobs& jobs, hipStream_t st, con
   return MI_OK;
 }
 
-// out[r][c] (ld = ldo) = sum_s slab[s][r][c]   (fixed order)
-static __global__ void slab_reduce_ld_kernel(const float* __restrict__ slab, int n_slab, int64_t rows, int64_t cols,
-                                      float* __restrict__ out, int64_t ldo) {
+// out[r][c] (ld = ldo) = sum_s slab[s][r][c]   (fixed order).  One float4 per thread when the shapes allow (the
+// slabs' loads are independent, only the adds are ordered), grid-stride scalar loop otherwise.
+static __global__ __launch_bounds__(256) void slab_reduce_ld_kernel(const float* __restrict__ slab, int n_slab,
+                                                                    int64_t rows, int64_t cols,
+                                                                    float* __restrict__ out, int64_t ldo, int vec) {
   const int64_t total = rows * cols;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  if (vec) {
+    for (int64_t e = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; e < total; e += stride * 4) {
+      f32x4 a = *reinterpret_cast<const f32x4*>(slab + e);
+      int s = 1;
+      for (; s + 3 < n_slab; s += 4) {
+        const f32x4 b0 = *reinterpret_cast<const f32x4*>(slab + (int64_t)s * total + e);
+        const f32x4 b1 = *reinterpret_cast<const f32x4*>(slab + (int64_t)(s + 1) * total + e);
+        const f32x4 b2 = *reinterpret_cast<const f32x4*>(slab + (int64_t)(s + 2) * total + e);
+        const f32x4 b3 = *reinterpret_cast<const f32x4*>(slab + (int64_t)(s + 3) * total + e);
+        a += b0;
+        a += b1;
+        a += b2;
+        a += b3;
+      }
+      for (; s < n_slab; ++s) a += *reinterpret_cast<const f32x4*>(slab + (int64_t)s * total + e);
+      *reinterpret_cast<f32x4*>(out + (e / cols) * ldo + (e % cols)) = a;
+    }
+    return;
+  }
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
     float a = slab[e];
     for (int s = 1; s < n_slab; ++s) a += slab[(int64_t)s * total + e];
     out[(e / cols) * ldo + (e % cols)] = a;
   }
+}
+
+static inline int launch_slab_reduce_ld(const float* slab, int n_slab, int64_t rows, int64_t cols, float* out,
+                                        int64_t ldo, hipStream_t st, const char* what) {
+  const int64_t total = rows * cols;
+  if (total <= 0) return MI_OK;
+  const int vec = (cols % 4 == 0 && ldo % 4 == 0 && ((uintptr_t)slab % 16 == 0) && ((uintptr_t)out % 16 == 0)) ? 1 : 0;
+  int64_t work = vec ? total / 4 : total;
+  int64_t blocks = (work + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  {
+    ProfScope prof_(what, st);
+    hipLaunchKernelGGL(slab_reduce_ld_kernel, dim3((unsigned)blocks), dim3(256), 0, st, slab, n_slab, rows, cols, out,
+                       ldo, vec);
+  }
+  MI_LAUNCH_CHECK(what);
+  return MI_OK;
 }
 
 }  // namespace mi
