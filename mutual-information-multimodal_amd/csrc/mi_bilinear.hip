@@ -290,3 +290,11 @@ int mi_bilinear_bwd(const float* x, const float* y, const float* w, const int64_
 }
 
 }  // extern "C"
+
+#ifdef MI_STAMPS
+// diagnostic build only: where the stamped kernels of this translation unit write their s_memtime values
+extern "C" int mi_debug_set_stamps(void* buf) {
+  mi::g_stamp_buf = (unsigned long long*)buf;
+  return 0;
+}
+#endif

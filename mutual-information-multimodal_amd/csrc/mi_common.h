@@ -4,6 +4,8 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <math.h>
+#include <string.h>
+#include <stdlib.h>
 
 #include "../../include/mi_critic.h"
 

@@ -13,6 +13,32 @@
 
 namespace mi {
 
+// Diagnostic build only (make STAMPS=1 -> lib_stamps/, never loaded by the package): s_memtime stamps of workgroup
+// phases into a side buffer that no kernel reads (scratch/stamps.py prints the medians).
+#ifdef MI_STAMPS
+static __device__ unsigned long long* g_stamps;
+static unsigned long long* g_stamp_buf = nullptr;
+static inline void stamp_select(const char* what, hipStream_t st) {
+  const char* f = getenv("MI_STAMP_KERNEL");
+  unsigned long long* p = (g_stamp_buf && f && strstr(what, f)) ? g_stamp_buf : nullptr;
+  (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(g_stamps), &p, sizeof(p), 0, hipMemcpyHostToDevice, st);
+}
+#define MI_STAMP(slot)                                                                                           \
+  do {                                                                                                           \
+    if (threadIdx.x == 0 && g_stamps)                                                                            \
+      g_stamps[((size_t)blockIdx.x + gridDim.x * (blockIdx.y + (size_t)gridDim.y * blockIdx.z)) * 8 + (slot)] =  \
+          __builtin_amdgcn_s_memtime();                                                                          \
+  } while (0)
+#define MI_STAMP_SELECT(what, st)                                         \
+  do {                                                                    \
+    stamp_select(what, st);                                               \
+    args.exp_mode = getenv("MI_EXP") ? atoi(getenv("MI_EXP")) : 0;        \
+  } while (0)
+#else
+#define MI_STAMP(slot) do {} while (0)
+#define MI_STAMP_SELECT(what, st) do {} while (0)
+#endif
+
 constexpr int kG2KT = 64;   // k per tile
 constexpr int kG2LD = 72;   // LDS row pitch in bf16 elements
 
@@ -85,6 +111,7 @@ struct GemmBf16Args {
   GemmBf16Problem p[2];
   int n_problems;   // 1 or 2
   int64_t k_chunk;  // split-K chunk (multiple of 64) when n_problems == 1 and gridDim.z > 1; else >= k
+  int exp_mode;        // diagnostic (MI_STAMPS) builds only
   int flat;            // 1: 1-D grid, problem / split / tile decoded from blockIdx.x (set by launch_gemm_bf16_flat)
   int xcd_gy, xcd_gx;  // set by the launcher: 8 = xcd_gy * xcd_gx blocks of the tile grid, one per XCD (0: row panels)
 };
@@ -599,6 +626,243 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_glds_kernel(GemmBf16Args arg
   epi(acc, m0 + wm * 64, n0 + wn * 64, P.m, P.n, prob, zsplit, smem_raw + wave * kEpiLdsPerWave);
 }
 
+// ------------------------------------------------------------------------------------------------ pipelined kernel
+// In-kernel s_memtime stamps of the double-buffered kernels above (profiles/README.md, r1_c): a 128 x 128 x 64 step
+// took ~1,800 cycles against 512 cycles of MFMA per SIMD, and it took that long TWICE over -- with the LDS-DMA removed
+// (one wave per SIMD exposes every ds_read latency) and with the MFMAs removed (one K tile in flight per workgroup:
+// ~2,200 cycles of load latency per tile).  This kernel addresses both:
+//   * three LDS stages, two K tiles in flight: the wait before a tile is a counted s_waitcnt vmcnt(pieces of ONE tile),
+//     followed by a bare s_barrier (hipcc's __syncthreads would drain vmcnt to 0);
+//   * always 8 waves = two per SIMD, so one wave's fragment waits overlap the other's MFMAs.
+// Two shapes:
+//   128 x 128 tile, K tile 64, waves 2 x 2 x 2 K groups (waves 4..7 take the second half of every K tile; the two
+//     partial accumulators are added through LDS before the epilogue)           -- long-K problems with few tiles
+//   256 x 256 tile, K tile 32, waves 2 x 4, each 128 x 64                      -- the K = d problems over B x B
+// A stage is 32 KB either way (96 KB of LDS, one workgroup per CU); every wave issues 4 LDS-DMA pieces per K tile.
+// Swizzle: chunk c (16 bytes) of row r sits at chunk position c ^ f(r), f(r) = (r >> 1) & 7 for 128-byte rows and
+// (r >> 2) & 3 for 64-byte rows: conflict-free for the lane groups ds_read_b128 serves per LDS cycle.
+template <int BM_, int BN_, int KT_, int WM_, int WN_, int KG_>
+struct PipeCfg {
+  static constexpr int BM = BM_, BN = BN_, KT = KT_, WM = WM_, WN = WN_, KG = KG_;
+  static constexpr int NW = WM * WN * KG;                 // waves
+  static constexpr int TM = BM / WM / 32, TN = BN / WN / 32;  // MFMA tiles per wave
+  static constexpr int ROWB = KT * 2;                     // bytes per LDS row
+  static constexpr int CPR = ROWB / 16;                   // 16-byte chunks per row
+  static constexpr int RPP = 1024 / ROWB;                 // rows per LDS-DMA piece
+  static constexpr int STAGE = (BM + BN) * ROWB;          // bytes per stage
+  static constexpr int STAGES = 3;
+  static constexpr int PIECES = STAGE / 1024 / NW;        // pieces per wave and K tile
+  static constexpr int APIECES = BM * ROWB / 1024;        // pieces 0 .. APIECES-1 belong to A
+  static constexpr int KK = KT / 16 / KG;                 // MFMA K steps per wave and K tile
+  static constexpr size_t SMEM = (size_t)STAGES * STAGE;
+  static_assert(NW == 8 && PIECES * NW * 1024 == STAGE && TN == 2 && (TM == 2 || TM == 4), "unsupported shape");
+  __device__ static __forceinline__ int swz(int row) { return KT == 64 ? (row >> 1) & 7 : (row >> 2) & 3; }
+};
+using PipeCfg128 = PipeCfg<128, 128, 64, 2, 2, 2>;
+using PipeCfg256 = PipeCfg<256, 256, 32, 2, 4, 1>;
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt_barrier() {
+  // counted wait for this wave's own pieces, then the workgroup barrier; "memory" keeps LDS accesses on their side
+  asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
+}
+
+template <class Cfg, class Epi>
+__global__ __launch_bounds__(512, 1) void gemm_bf16_pipe_kernel(GemmBf16Args args, Epi epi) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  int prob, zsplit, bx_, by_;
+  int64_t k_chunk = args.k_chunk;
+  if (args.flat) {
+    const int L = (int)blockIdx.x;
+    prob = (args.n_problems == 2 && L >= args.p[1].wg_begin) ? 1 : 0;
+    const GemmBf16Problem& Q = args.p[prob];
+    const int local = L - Q.wg_begin, tiles = Q.nx * Q.ny;
+    zsplit = local / tiles;
+    xcd_tile_lin(local - zsplit * tiles, Q.nx, Q.ny, bx_, by_);
+    k_chunk = Q.k_chunk;
+  } else {
+    prob = (int)blockIdx.z % args.n_problems;
+    zsplit = (int)blockIdx.z / args.n_problems;
+    if (args.xcd_gy) xcd_block_tile(args.xcd_gy, args.xcd_gx, bx_, by_);
+    else xcd_tile(bx_, by_);
+  }
+  const GemmBf16Problem& P = args.p[prob];
+  const int64_t m0 = (int64_t)by_ * Cfg::BM, n0 = (int64_t)bx_ * Cfg::BN;
+  if (m0 >= P.m || n0 >= P.n) return;
+  const int64_t kbeg = (int64_t)zsplit * k_chunk;
+  if (kbeg >= P.k) return;  // flat launches: padding ids between the problems' ranges
+  int64_t kend = kbeg + k_chunk;
+  if (kend > P.k) kend = P.k;
+
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int kgrp = wave / (Cfg::WM * Cfg::WN), wmn = wave % (Cfg::WM * Cfg::WN);
+  const int wm = wmn / Cfg::WN, wn = wmn % Cfg::WN;
+  const int r32 = lane & 31, half = lane >> 5;
+
+  // LDS-DMA pieces of this wave: piece q = PIECES * wave + i; a piece is RPP rows of ROWB bytes
+  const char* src[Cfg::PIECES];
+  int dst[Cfg::PIECES];
+#pragma unroll
+  for (int i = 0; i < Cfg::PIECES; ++i) {
+    const int q = Cfg::PIECES * wave + i;
+    const bool is_b = q >= Cfg::APIECES;
+    const int ql = is_b ? q - Cfg::APIECES : q;
+    const int row = ql * Cfg::RPP + lane / Cfg::CPR;
+    const int chunk = (lane % Cfg::CPR) ^ Cfg::swz(row);
+    int64_t g = (is_b ? n0 : m0) + row;
+    const int64_t lim = is_b ? P.n : P.m;
+    if (g >= lim) g = lim - 1;  // clamped rows only feed outputs the epilogue drops
+#ifdef MI_STAMPS
+    if (args.exp_mode == 95) g &= 255;               // diagnostic: every tile reads the same 256 rows (L2-resident)
+    if (args.exp_mode == 94 && !is_b) g &= 255;      // ... only A
+    if (args.exp_mode == 93 && is_b) g &= 127;       // ... only B
+#endif
+    const bf16_t* base = is_b ? P.b + g * P.ldb : P.a + g * P.lda;
+    src[i] = reinterpret_cast<const char*>(base + kbeg) + chunk * 16;
+    dst[i] = (is_b ? Cfg::BM * Cfg::ROWB : 0) + ql * 1024;
+  }
+  auto issue_piece = [&](int64_t t, int stage, int i) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[i] + t * Cfg::ROWB),
+                                     (__attribute__((address_space(3))) void*)(smem_raw + stage * Cfg::STAGE + dst[i]),
+                                     16, 0, 0);
+  };
+
+  f32x16 acc[Cfg::TM / 2][2][2];
+#pragma unroll
+  for (int h = 0; h < Cfg::TM / 2; ++h)
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[h][a][b][r] = 0.0f;
+
+  int aoff[Cfg::TM], aswz[Cfg::TM], boff[2], bswz[2];
+#pragma unroll
+  for (int t = 0; t < Cfg::TM; ++t) {
+    const int ar = wm * (Cfg::BM / Cfg::WM) + t * 32 + r32;
+    aoff[t] = ar * Cfg::ROWB;
+    aswz[t] = Cfg::swz(ar);
+  }
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int br_ = wn * (Cfg::BN / Cfg::WN) + t * 32 + r32;
+    boff[t] = Cfg::BM * Cfg::ROWB + br_ * Cfg::ROWB;
+    bswz[t] = Cfg::swz(br_);
+  }
+
+  const int64_t nt = (kend - kbeg) / Cfg::KT;
+  MI_STAMP(0);
+#pragma unroll
+  for (int i = 0; i < Cfg::PIECES; ++i)
+    if (nt > 0) issue_piece(0, 0, i);
+#pragma unroll
+  for (int i = 0; i < Cfg::PIECES; ++i)
+    if (nt > 1) issue_piece(1, 1, i);
+  if (nt > 1) wait_vmcnt_barrier<Cfg::PIECES>();  // tile 0 has landed (every wave's pieces)
+  else wait_vmcnt_barrier<0>();
+  MI_STAMP(1);
+
+  // Ping-pong schedule.  Issuing LDS-DMA pieces holds a wave for hundreds of cycles (the stamps: ~180 per piece with
+  // eight waves issuing at once), and behind one barrier per K tile both waves of a SIMD sit in that phase together,
+  // then compete for the MFMA pipe together.  Here the waves form two groups, one wave per SIMD each, half an
+  // iteration apart: while one group is in its memory phase (fragment reads of tile t, LDS-DMA for tile t + 2, wait
+  // for its pieces of tile t + 1) the other runs the MFMAs of its tile, and a barrier ends every phase.
+  //   phase:    0        1        2        3      ...   2 nt
+  //   group 0:  MEM(0)   MMA(0)   MEM(1)   MMA(1) ...   -
+  //   group 1:  -        MEM(0)   MMA(0)   MEM(1) ...   MMA(nt - 1)
+  // Tile t is read in phases 2t (group 0) and 2t + 1 (group 1); every wave has waited for its own pieces of it by the
+  // end of phase 2t - 1, and its stage is refilled (tile t + 3) from phase 2t + 2 on.
+  const int grp = wave >> 2;  // waves w and w + 4 share a SIMD
+  constexpr int NM = Cfg::TM * 2;  // MFMAs per 16-deep step
+  bf16x8 af[Cfg::KK][Cfg::TM], bfr[Cfg::KK][2];
+  const int kk0 = kgrp * Cfg::KK;
+  if (grp == 1) asm volatile("s_barrier" ::: "memory");  // phase 0 belongs to group 0
+  int stage = 0;
+  for (int64_t t = 0; t < nt; ++t) {
+    if (t == nt / 4) MI_STAMP(2);
+    if (t == (3 * nt) / 4) MI_STAMP(3);
+    // ---- memory phase
+    const char* sb = smem_raw + stage * Cfg::STAGE;
+#pragma unroll
+    for (int q = 0; q < Cfg::KK; ++q) {
+#pragma unroll
+      for (int tm = 0; tm < Cfg::TM; ++tm)
+        af[q][tm] = *reinterpret_cast<const bf16x8*>(sb + aoff[tm] + 16 * ((2 * (kk0 + q) + half) ^ aswz[tm]));
+#pragma unroll
+      for (int tn = 0; tn < 2; ++tn)
+        bfr[q][tn] = *reinterpret_cast<const bf16x8*>(sb + boff[tn] + 16 * ((2 * (kk0 + q) + half) ^ bswz[tn]));
+    }
+    const int nstage = stage >= 1 ? stage - 1 : 2;  // (stage + 2) % 3
+    if (t + 2 < nt) {
+#pragma unroll
+      for (int i = 0; i < Cfg::PIECES; ++i) issue_piece(t + 2, nstage, i);
+      wait_vmcnt_barrier<Cfg::PIECES>();  // own pieces of tile t + 1 done; end of the phase
+    } else {
+      wait_vmcnt_barrier<0>();
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- MFMA phase (the fragment reads had the whole barrier to land)
+#pragma unroll
+    for (int q = 0; q < Cfg::KK; ++q)
+#pragma unroll
+      for (int m = 0; m < NM; ++m) {
+        const int tm = m >> 1, tn = m & 1;
+        acc[tm >> 1][tm & 1][tn] =
+            __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[q][tm], bfr[q][tn], acc[tm >> 1][tm & 1][tn], 0, 0, 0);
+      }
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_barrier" ::: "memory");  // end of the phase
+    stage = stage == 2 ? 0 : stage + 1;
+  }
+  if (grp == 0) asm volatile("s_barrier" ::: "memory");  // phase 2 nt belongs to group 1
+  __syncthreads();  // all fragment reads done: the stages are free for the K-group reduction and the epilogue staging
+  MI_STAMP(4);
+  if constexpr (Cfg::KG == 2) {
+    // add the second K group's accumulators: [wmn][register 0..63][lane] fp32 = 64 KB
+    float* red = reinterpret_cast<float*>(smem_raw) + wmn * 4096 + lane;
+    if (kgrp == 1) {
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) red[((a * 2 + b) * 16 + r) * 64] = acc[0][a][b][r];
+    }
+    __syncthreads();
+    if (kgrp == 0) {
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[0][a][b][r] += red[((a * 2 + b) * 16 + r) * 64];
+    }
+    __syncthreads();  // the epilogue's staging areas overlap other waves' parts of `red`
+    if (kgrp == 1) return;
+  }
+  const int64_t mb = m0 + wm * (Cfg::BM / Cfg::WM), nb = n0 + wn * (Cfg::BN / Cfg::WN);
+  char* lds = smem_raw + wmn * kEpiLdsPerWave;
+  if constexpr (Epi::kReducesPartial) {
+    static_assert(Cfg::KG == 1, "reducing epilogues run on all waves");
+    __shared__ Partial scratch[8];
+    Partial p = epi.lane_partial(acc[0], mb, nb, P.m, P.n);
+    if constexpr (Cfg::TM == 4) {
+      const Partial q = epi.lane_partial(acc[Cfg::TM / 2 - 1], mb + 64, nb, P.m, P.n);
+      lse_merge(p.m, p.s, q.m, q.s);
+      p.pos += q.pos;
+      p.cnt += q.cnt;
+    }
+    p = block_reduce_partial<8>(p, scratch);
+    if (threadIdx.x == 0) epi.partials[(int64_t)blockIdx.y * gridDim.x + blockIdx.x] = p;
+  } else {
+    epi(acc[0], mb, nb, P.m, P.n, prob, zsplit, lds);
+    if constexpr (Cfg::TM == 4) epi(acc[Cfg::TM / 2 - 1], mb + 64, nb, P.m, P.n, prob, zsplit, lds);
+  }
+  MI_STAMP(5);
+}
+
 // ------------------------------------------------------------------------------------------------ 256 x 256 tiles
 // The K = d (512) GEMMs over the B x B score matrix (score+LSE, G) are bound by LDS ingest per CU, not by MFMA issue:
 // a 128 x 128 tile moves 32 KB per 64-deep K step for 2 MFLOP.  A 256 x 256 tile doubles the flops per ingested byte
@@ -722,6 +986,10 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_big_kernel(GemmBf16Args args
 constexpr size_t kG2SmemBig = 2 * 2 * 32768;  // 131,072 bytes
 
 // number of workgroup partials a reducing epilogue writes for an M x N problem (the launcher picks the tile size)
+static inline bool gemm_old_kernels() {  // A/B switch: the double-buffered kernels instead of the pipelined one
+  static const bool v = getenv("MI_GEMM_OLD") != nullptr;
+  return v;
+}
 static inline bool gemm_bf16_use_big(int64_t m, int64_t n, int64_t k) {
   static const bool off = getenv("MI_GEMM_NO_BIG") != nullptr;
   return !off && k % kG2KT == 0 && k > 0 && ((m + 255) / 256) * ((n + 255) / 256) >= 192;
@@ -754,6 +1022,11 @@ static inline int launch_gemm_bf16(const GemmBf16Args& args_in, int n_splits, co
     e = hipFuncSetAttribute((const void*)gemm_bf16_glds_kernel<Epi>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)kG2SmemGlds);
     if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(gemm_bf16_glds_kernel)");
+    if constexpr (!Epi::kReducesPartial) {
+      e = hipFuncSetAttribute((const void*)gemm_bf16_pipe_kernel<PipeCfg128, Epi>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)PipeCfg128::SMEM);
+      if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(gemm_bf16_pipe_kernel 128)");
+    }
     attr_set = true;
   }
   bool dma_ok = args.k_chunk % kG2KT == 0 || n_splits == 1;
@@ -768,6 +1041,7 @@ static inline int launch_gemm_bf16(const GemmBf16Args& args_in, int n_splits, co
     }
     dim3 grid((unsigned)((nn + 255) / 256), (unsigned)((mm + 255) / 256), 1);
     xcd_pick_blocks(grid.y, grid.x, 256, args.p[0].k, 1, args.xcd_gy, args.xcd_gx);
+    MI_STAMP_SELECT(what, st);
     {
       ProfScope prof_(what, st);
       hipLaunchKernelGGL((gemm_bf16_big_kernel<Epi>), grid, dim3(512), kG2SmemBig, st, args, epi);
@@ -778,9 +1052,20 @@ static inline int launch_gemm_bf16(const GemmBf16Args& args_in, int n_splits, co
   dim3 grid((unsigned)((nn + kTile - 1) / kTile), (unsigned)((mm + kTile - 1) / kTile),
             (unsigned)(args.n_problems * n_splits));
   xcd_pick_blocks(grid.y, grid.x, kTile, args.p[0].k, (int)grid.z, args.xcd_gy, args.xcd_gx);
+  MI_STAMP_SELECT(what, st);
   {
     ProfScope prof_(what, st);
-    if (dma_ok) hipLaunchKernelGGL((gemm_bf16_glds_kernel<Epi>), grid, dim3(256), kG2SmemGlds, st, args, epi);
+    bool piped = false;
+    if constexpr (!Epi::kReducesPartial) {
+      // measured (profiles/README.md): the ping-pong kernel wins on the long-K launch that has one workgroup per CU
+      // (dT | dY: 51.5 -> 43.3 us) and loses where two 4-wave workgroups per CU fit (T, dW | dX) or K is short
+      piped = dma_ok && !gemm_old_kernels() && args.p[0].k >= 2048 &&
+              (int64_t)grid.x * grid.y * grid.z <= 256;
+      if (piped)
+        hipLaunchKernelGGL((gemm_bf16_pipe_kernel<PipeCfg128, Epi>), grid, dim3(512), PipeCfg128::SMEM, st, args, epi);
+    }
+    if (piped) {
+    } else if (dma_ok) hipLaunchKernelGGL((gemm_bf16_glds_kernel<Epi>), grid, dim3(256), kG2SmemGlds, st, args, epi);
     else hipLaunchKernelGGL((gemm_bf16_kernel<Epi>), grid, dim3(256), kG2Smem, st, args, epi);
   }
   MI_LAUNCH_CHECK(what);
@@ -816,6 +1101,7 @@ static inline int launch_gemm_bf16_flat(const GemmBf16Args& args_in, const int (
   args.flat = 1;
   args.xcd_gy = args.xcd_gx = 0;
   args.k_chunk = 0;
+  MI_STAMP_SELECT(what, st);
   {
     ProfScope prof_(what, st);
     hipLaunchKernelGGL((gemm_bf16_glds_kernel<Epi>), dim3((unsigned)total), dim3(256), kG2SmemGlds, st, args, epi);
