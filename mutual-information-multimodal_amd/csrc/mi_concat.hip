@@ -54,7 +54,7 @@ static ConcatPlan plan_concat(Workspace& ws, int64_t br, int64_t b, int64_t h1, 
   p.w2bf = (precision == MI_PREC_BF16) ? ws.take<bf16_t>(h2 * h1) : nullptr;
   p.partials = ws.take<Partial>(kMatrixPartialBlocks);
   if (need_grad) {
-    p.bitsP = ws.take<unsigned long long>(br * b * (h2 / 64));
+    p.bitsP = ws.take<unsigned long long>(bitsp_words(br, b, h2));
     p.bitsN = ws.take<unsigned>(br * ((b + 31) / 32) * h2);
     const int kc = (precision == MI_PREC_BF16) ? DuvCfg<bf16_t>::KC : DuvCfg<float>::KC;
     const int64_t n_kc = (h1 + kc - 1) / kc;

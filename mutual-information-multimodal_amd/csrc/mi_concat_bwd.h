@@ -160,7 +160,7 @@ __global__ __launch_bounds__(512) void concat_bwd_duv_kernel(
       const bool ok = li < b_rows && gj < jhi;
 #pragma unroll
       for (int pw = 0; pw < 4; ++pw)
-        words[m][pw] = (ok && pw < hw) ? bitsP[(li * b + gj) * wpp + h * hw + pw] : 0ull;
+        words[m][pw] = (ok && pw < hw) ? bitsP[bitsp_index(li, gj, h, pw, (b + 31) / 32, hw)] : 0ull;
     }
     // ---- (b) g tile and -V tile -------------------------------------------------------------------------------------
     {

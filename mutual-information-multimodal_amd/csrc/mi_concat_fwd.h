@@ -9,8 +9,13 @@
 // so the [B^2, H1] activation matrix of the reference (34 GB in bf16 at B = 4096) never exists.  The epilogue applies
 // relu and the dot with w3 in registers (b2 is the accumulator's initial value), and, when gradients are needed,
 // emits the sign pattern of Z2 as two bit images used by the backward kernels (1 bit per (pair, n), twice):
-//     bitsP: per pair, 64-bit words indexed [h][pw], pw = n / 128; bit q = 16*a + r  <->  n = 128*pw + 32*a +
-//            (r & 3) + 8*(r >> 2) + 4*h        (lane-local MFMA accumulator order; consumed by mi_concat_bwd dU/dV)
+//     bitsP: one 64-bit word per (pair, lane half h, pw = n / 128); bit q = 16*a + r  <->  n = 128*pw + 32*a +
+//            (r & 3) + 8*(r >> 2) + 4*h        (lane-local MFMA accumulator order; consumed by mi_concat_bwd dU/dV).
+//            Stored as [row][32-column block][pw][h][column % 32] (bitsp_index): the 64 lanes of a wave hold 32
+//            consecutive columns x 2 halves of one (row, pw), so one store instruction writes 512 contiguous bytes.
+//            (The earlier per-pair layout [pair][h][pw] made every store a scatter of 8-byte pieces into lines that
+//            were completed a pass later: 16.8 GB of read-for-ownership fetches and 5.6 GB of writes per forward at
+//            B = 4096 for 1 GB of payload -- profiles/r1_c_pmc_traffic.json.)
 //     bitsN: per (row i, 32-column block), one 32-bit word per n; bit q <-> column 32*block + q   (consumed by dW2)
 // Wave (wn, wp): hidden units [128 wn, +128) of the pass, pairs of local rows {2 wp, 2 wp + 1} x 32 columns:
 // 4 x 2 MFMA 32x32 tiles, 128 accumulator registers.
@@ -24,6 +29,16 @@
 #include <utility>
 
 #include "mi_common.h"
+
+namespace mi {
+// word index into bitsP; jb32 = ceil(B / 32), hw = H2 / 128
+__host__ __device__ __forceinline__ int64_t bitsp_index(int64_t li, int64_t gj, int h, int pw, int64_t jb32, int hw) {
+  return ((((li * jb32 + (gj >> 5)) * hw + pw) * 2 + h) << 5) + (gj & 31);
+}
+static inline int64_t bitsp_words(int64_t b_rows, int64_t b, int64_t h2) {
+  return b_rows * ((b + 31) / 32) * (h2 / 128) * 64;
+}
+}  // namespace mi
 
 namespace mi {
 
@@ -300,7 +315,7 @@ __global__ __launch_bounds__(256 * NWN, 2) /* 2 waves per SIMD: <= 256 registers
       }
       if (bitsP && li < b_rows && gj < b) {
         const int64_t wpp = H2 / 64;  // 64-bit words per pair
-        bitsP[(li * b + gj) * wpp + h * (wpp / 2) + pw] = pbits;
+        bitsP[bitsp_index(li, gj, h, pw, (b + 31) / 32, (int)(wpp / 2))] = pbits;
       }
       s_total[t] += s;
     }

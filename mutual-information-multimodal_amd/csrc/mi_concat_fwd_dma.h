@@ -208,7 +208,7 @@ __global__ __launch_bounds__(256 * NWN, 2) void concat_fwd_dma_kernel(
       }
       if (bitsP && li < b_rows && gj < b) {
         const int64_t wpp = H2 / 64;
-        bitsP[(li * b + gj) * wpp + h * (wpp / 2) + pw] = pbits;
+        bitsP[bitsp_index(li, gj, h, pw, (b + 31) / 32, (int)(wpp / 2))] = pbits;
       }
       s_total[t] += s;
     }
