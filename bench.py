@@ -208,6 +208,39 @@ def profile_kernels(stepper, steps):
     return prof.by_name()
 
 
+# profiling-hook kernel name -> substring of the rocprofv3 kernel name in profiles/*_pmc_traffic.json
+PMC_KERNEL_OF = {
+    "bilinear dT = G Y | dY = G^T T": "gemm_bf16_pipe_kernel",
+    "bilinear G": "gemm_bf16_big_kernel<mi::EpiGradScore2>",
+    "bilinear score+LSE": "gemm_bf16_big_kernel<mi::EpiScoreLse2>",
+    "concat_fwd_kernel": "concat_fwd_dma_kernel",
+    "concat_bwd_duv_kernel": "concat_bwd_duv_kernel",
+    "concat_bwd_dw2_kernel": "concat_bwd_dw2_kernel",
+}
+
+
+def measured_traffic(name, b, d):
+    """HBM bytes per launch of a kernel from the newest committed PMC pass (tools/profile_round.sh; FETCH_SIZE and
+    WRITE_SIZE in separate rocprofv3 --pmc runs, gfx950 corrections applied there).  Only valid for the configuration
+    those passes ran (B=4096, d=512, one GPU); None otherwise -- bench.py itself cannot run the profiler."""
+    if (b, d) != (4096, 512) or name not in PMC_KERNEL_OF:
+        return None
+    import glob
+    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*_pmc_traffic.json")))
+    if not files:
+        return None
+    try:
+        with open(files[-1]) as f:
+            table = json.load(f)["kernels"]
+    except (OSError, ValueError, KeyError):
+        return None
+    for key, val in table.items():
+        if PMC_KERNEL_OF[name] in key:
+            return {"bytes": round(val["total_bytes"]), "fetch": round(val["fetch_bytes"]),
+                    "write": round(val["write_bytes"]), "source": os.path.basename(files[-1])}
+    return None
+
+
 def roofline_of(kernels, br, b, d, precision):
     if not kernels:
         return None
@@ -219,9 +252,10 @@ def roofline_of(kernels, br, b, d, precision):
                 "traffic": None, "avg_us": k["ms_avg"] * 1e3}
     achieved = fl / (k["ms_avg"] * 1e-3) / 1e12
     peak = PEAK_TFLOPS[precision]
+    tr = measured_traffic(name, b, d) if br == b else None
     return {"kernel": name, "bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
-            "frac": round(achieved / peak, 4), "traffic": None, "avg_us": round(k["ms_avg"] * 1e3, 2),
-            "flops_per_launch": fl}
+            "frac": round(achieved / peak, 4), "traffic": tr["bytes"] if tr else None, "traffic_detail": tr,
+            "avg_us": round(k["ms_avg"] * 1e3, 2), "flops_per_launch": fl}
 
 
 def cpu_baseline(kind, args):

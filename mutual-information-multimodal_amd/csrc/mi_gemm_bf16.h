@@ -14,7 +14,7 @@
 namespace mi {
 
 // Diagnostic build only (make STAMPS=1 -> lib_stamps/, never loaded by the package): s_memtime stamps of workgroup
-// phases into a side buffer that no kernel reads (scratch/stamps.py prints the medians).
+// phases into a side buffer that no kernel reads (tools/diag/stamps.py prints the medians).
 #ifdef MI_STAMPS
 static __device__ unsigned long long* g_stamps;
 static unsigned long long* g_stamp_buf = nullptr;
