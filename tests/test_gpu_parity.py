@@ -561,6 +561,55 @@ def test_concat_properties_b1024(dev):
     assert all(torch.equal(a, c) for a, c in zip(g1, g2))
 
 
+@pytest.mark.parametrize("b,d,est,dup", [(4096, 512, "infonce", "random"), (1024, 768, "dv", "survey")])
+def test_concat_full_size_sampled_rows_vs_oracle(dev, b, d, est, dup):
+    """BASELINE config 4 size (B=4096, d=512) and config 3 size (B=1024, d=768, the reference's own widths) with the
+    reference critic make_mlp(2d,[1024,512]), bf16 operands and duplicated study ids ("survey": SURVEY.md 8d's 12.5 %
+    variant, sid_i = i - (i mod 2) for i < B/8).  The oracle cannot run 16.8 M pairs, so: (1) the loss is re-derived on the CPU (fp64) from
+    the kernel's own full score matrix -- masking, log-sum-exp and the positive mean at full size; (2) the scores of a
+    few rows (all 4096 columns each) and (3) dL/dX of those rows (a row's gradient only needs that row's pairs and the
+    global log-sum-exp) are compared with the oracle that rounds at the same points."""
+    from mutual_info_img_txt import mi_critics
+    from mutual_info_img_txt.model import make_mlp
+    gen = torch.Generator().manual_seed(17)
+    x = torch.randn(b, d, generator=gen)
+    y = torch.randn(b, d, generator=gen)
+    if dup == "random":
+        sid = torch.randint(0, b // 2, (b,), generator=gen)
+    else:
+        sid = torch.arange(b)
+        sid[: b // 8] -= sid[: b // 8] % 2
+    torch.manual_seed(17)
+    mlp = make_mlp(2 * d, [1024, 512])
+    params = [p.detach().clone() for p in mlp.parameters()]
+    mlp.to(dev)
+    xl, yl = x.to(dev).requires_grad_(True), y.to(dev).requires_grad_(True)
+    loss, scores = mi_critics.fused_mi_bound(xl, yl, sid.to(dev), mlp, est, precision="bf16", return_scores=True)
+    loss.sum().backward()
+    s_k = scores.detach().cpu().double()
+    ref_loss = orc.bound_from_matrix(s_k, sid, est)
+    assert abs(float(loss) - float(ref_loss)) < 1e-4 * max(1.0, abs(float(ref_loss)))
+    # sampled rows: first / last, tile borders, and one row whose study id occurs more than once
+    codes = sid.numpy()
+    dup_row = int(np.flatnonzero(np.bincount(codes)[codes] > 1)[0])
+    rows = sorted({0, 7, 8, b // 2 - 1, b // 2, b - 1, dup_row})
+    p64 = [p.double() for p in params]
+    x_r = x[rows].double().requires_grad_(True)
+    s_r = orc.concat_scores_matrix(x_r, y.double(), p64, round_fn=orc.round_bf16)
+    sc = max(float(s_k.abs().max()), 1.0)
+    np.testing.assert_allclose(s_k[rows].numpy(), s_r.detach().numpy(), rtol=0, atol=3e-3 * sc)
+    neg = orc.negative_mask(sid)
+    lse = torch.logsumexp(s_k[neg], dim=0)
+    g = torch.where(neg[rows], torch.exp(s_r.detach() - lse), torch.zeros_like(s_r))
+    for k, r in enumerate(rows):
+        g[k, r] = -1.0 / b
+    s_r.backward(g)
+    got = xl.grad[rows].cpu().double()
+    scale = float(xl.grad.abs().max())
+    err = float((got - x_r.grad).abs().max()) / scale
+    assert err < 2e-2, err
+
+
 def test_train_synthetic_entry_point(dev, tmp_path):
     """train.py --synthetic (the reference's train_MI_models entry point, train.py:21-36) on the fused path: the
     bound improves (the loss falls) on correlated synthetic embeddings."""
