@@ -7,8 +7,11 @@
 * ``mi_discriminator`` -- ``make_mlp(d_img + d_txt, [1024, 512])`` as at reference main_utils.py:77;
 * ``mi_step(...)`` -- the body of the reference's inner loop, main_utils.py:220-226, on the fused HIP path.
 
-The encoders, datasets, optimisers' bookkeeping and checkpointing of the reference trainer (main_utils.py:112-268)
-are out of scope for this tier except for the synthetic-embedding loop in ``train`` used by ``train.py --synthetic``.
+``train`` is the reference's loop (main_utils.py:112-268) around that step: its three optimisers (Adam for the image
+encoder, Adam for the critic, AdamW without bias correction + warm-up-linear schedule for the text encoder), its
+zero_grad / backward / step order and its epoch log lines.  The encoders themselves, the datasets and the checkpoint
+files are out of scope for this tier: ``train`` takes any pair of ``nn.Module`` encoders (or none: the source then
+yields embeddings directly, as ``train.py --synthetic`` does).
 """
 from __future__ import annotations
 
@@ -20,6 +23,7 @@ import torch
 
 from . import _hip, mi_critics
 from .model import BilinearCritic, SeparableCritic, make_mlp
+from .optimization import AdamW, WarmupLinearSchedule
 
 
 class _CreatePairsFn(torch.autograd.Function):
@@ -82,7 +86,10 @@ class MultiModalManager:
     """Hot-path subset of the reference's MultiModalManager (main_utils.py:53-268)."""
 
     def __init__(self, d_img: int = 768, d_txt: int = 768, critic: str = "concat_mlp", hidden_dims=(1024, 512),
-                 d_proj: int = 256):
+                 d_proj: int = 256, image_model=None, text_model=None):
+        # optional encoders (the reference's self.model.image_model / text_model, model.py:540-555): any modules that
+        # map a batch to [B, d_img] / [B, d_txt] fp32 embeddings
+        self.image_model, self.text_model = image_model, text_model
         if critic == "concat_mlp":
             self.mi_discriminator = make_mlp(d_img + d_txt, list(hidden_dims))  # reference main_utils.py:77
         elif critic == "bilinear":
@@ -119,24 +126,54 @@ class MultiModalManager:
         return critic(mi_output, len(study_id), embedding_img.device)
 
     def train(self, embedding_source, device, args):
-        """Synthetic-embedding training loop with the reference's step order (main_utils.py:189-235): zero_grad,
-        forward, loss.backward(), optimizer step, epoch loss = sum of step losses, and its two log lines.
-        ``embedding_source(step) -> (embedding_img, embedding_txt, study_id)`` stands in for the encoders."""
+        """The reference's training loop (main_utils.py:112-268) around the fused MI step.
+
+        ``embedding_source(step) -> (img, txt, study_id)``: with encoders attached, ``img`` / ``txt`` are the encoders'
+        inputs (one batch, ``drop_last`` batching as main_utils.py:127-129); without, they are the embeddings.
+        Optimisers and order as the reference: Adam(image encoder, init_lr), Adam(critic, init_lr), AdamW(text encoder,
+        lr 2e-5, weight decay 0.1 except bias / LayerNorm, no bias correction) with a warm-up-linear schedule over
+        ``num_train_epochs * steps_per_epoch`` steps (10 % warm-up) -- main_utils.py:152-172; per step: zero_grad of
+        all three, forward, ``loss.backward()``, then critic, image, text optimiser steps and the scheduler step --
+        main_utils.py:205-229.  Epoch loss = sum of the step losses; the reference's two log lines per epoch."""
         logger = logging.getLogger(__name__)
         mi_critics._estimator_code(args.mi_estimator)  # eager validation (the reference fails late, main_utils.py:224)
         self.mi_discriminator = self.mi_discriminator.to(device)
         mi_optimizer = torch.optim.Adam(self.mi_discriminator.parameters(), lr=args.init_lr)  # main_utils.py:153
+        img_optimizer = txt_optimizer = scheduler = None
+        if self.image_model is not None:
+            self.image_model = self.image_model.to(device).train()
+            img_optimizer = torch.optim.Adam(self.image_model.parameters(), lr=args.init_lr)  # main_utils.py:152
+        if self.text_model is not None:
+            self.text_model = self.text_model.to(device).train()
+            no_decay = ['bias', 'LayerNorm.bias', 'LayerNorm.weight']  # main_utils.py:158-165
+            param_txt = list(self.text_model.named_parameters())
+            grouped = [{'params': [p for n, p in param_txt if not any(nd in n for nd in no_decay)], 'weight_decay': 0.1},
+                       {'params': [p for n, p in param_txt if any(nd in n for nd in no_decay)], 'weight_decay': 0.0}]
+            txt_optimizer = AdamW(grouped, lr=getattr(args, "txt_lr", 2e-5), correct_bias=False)
+            num_train_steps = int(args.num_train_epochs * args.steps_per_epoch)
+            scheduler = WarmupLinearSchedule(txt_optimizer, warmup_steps=0.1 * num_train_steps, t_total=num_train_steps)
+        precision = getattr(args, "precision", "bf16")
         training_loss = []
         for epoch in range(int(args.num_train_epochs)):
             start_time = time.time()
             epoch_loss = torch.zeros((), device=device)
             for step in range(int(args.steps_per_epoch)):
-                embedding_img, embedding_txt, study_id = embedding_source(step)
+                img, txt, study_id = embedding_source(step)
+                if img_optimizer is not None:
+                    img_optimizer.zero_grad()
+                if txt_optimizer is not None:
+                    txt_optimizer.zero_grad()
                 mi_optimizer.zero_grad()
-                loss = self.mi_step(embedding_img, embedding_txt, study_id, args.mi_estimator,
-                                    getattr(args, "precision", "bf16"))
+                embedding_img = self.image_model(img) if self.image_model is not None else img
+                embedding_txt = self.text_model(txt) if self.text_model is not None else txt
+                loss = self.mi_step(embedding_img, embedding_txt, study_id, args.mi_estimator, precision)
                 loss.sum().backward()
                 mi_optimizer.step()
+                if img_optimizer is not None:
+                    img_optimizer.step()
+                if txt_optimizer is not None:
+                    txt_optimizer.step()
+                    scheduler.step()
                 epoch_loss += loss.detach().sum()  # device-side accumulation; one sync per epoch
             epoch_loss = float(epoch_loss.item())
             training_loss.append(epoch_loss)

@@ -319,3 +319,27 @@ def synthetic_case(b: int, d_img: int, d_txt: int, h1: int = 1024, h2: int = 512
         for n in range(max(b // 8, min(b, 4))):
             sid[n] = str(50000000 + n - (n % 2))
     return x, y, sid, [w1, b1, w2, b2, w3, b3]
+
+
+# ------------------------------------------------------------------------------------------------ trainer pieces (f1)
+def adamw_step(p, g, m, v, t, lr, betas=(0.9, 0.999), eps=1e-6, weight_decay=0.0, correct_bias=True):
+    """One step of pytorch-transformers==1.0.0 ``optimization.AdamW`` (the optimiser of the reference's text encoder,
+    main_utils.py:166-168; the package is absent here, this restates its published algorithm) on numpy float64 arrays.
+    ``t`` is the 1-based step count.  Returns the new (p, m, v)."""
+    b1, b2 = betas
+    m = b1 * m + (1.0 - b1) * g
+    v = b2 * v + (1.0 - b2) * g * g
+    step = lr
+    if correct_bias:
+        step = lr * np.sqrt(1.0 - b2 ** t) / (1.0 - b1 ** t)
+    p = p - step * m / (np.sqrt(v) + eps)
+    if weight_decay > 0.0:
+        p = p - lr * weight_decay * p
+    return p, m, v
+
+
+def warmup_linear(step, warmup_steps, t_total):
+    """Multiplier of pytorch-transformers==1.0.0 ``WarmupLinearSchedule`` (main_utils.py:170-172)."""
+    if step < warmup_steps:
+        return float(step) / float(max(1, warmup_steps))
+    return max(0.0, float(t_total - step) / float(max(1.0, t_total - warmup_steps)))
