@@ -561,6 +561,35 @@ def test_concat_properties_b1024(dev):
     assert all(torch.equal(a, c) for a, c in zip(g1, g2))
 
 
+@pytest.mark.parametrize("b,dx,dy", [(3648, 64, 64), (3608, 128, 64), (4096, 64, 192)])
+def test_bilinear_large_ragged_vs_oracle(dev, b, dx, dy):
+    """Batches that select the 256 x 256-tile and ping-pong kernels but are not multiples of their tiles (3648 = 57 * 64:
+    partial 256- and 128-row tiles; 3608 = 8 * 451: K of the long products is not a multiple of 64, so those fall back to
+    the register-staged kernel) and widths below / across one tile.  bf16 mode against the oracle."""
+    from mutual_info_img_txt import _hip, mi_critics
+    from mutual_info_img_txt.model import BilinearCritic
+    gen = torch.Generator().manual_seed(b + dx)
+    x = torch.randn(b, dx, generator=gen)
+    y = torch.randn(b, dy, generator=gen)
+    w = torch.randn(dx, dy, generator=gen) * (0.5 / (dx * dy) ** 0.25)
+    sid = torch.randint(0, b // 2, (b,), generator=gen)
+    critic = BilinearCritic(dx, dy)
+    with torch.no_grad():
+        critic.weight.copy_(w)
+    critic.to(dev)
+    xl, yl = x.to(dev).requires_grad_(True), y.to(dev).requires_grad_(True)
+    loss, stats = mi_critics.fused_mi_bound(xl, yl, sid.to(dev), critic, "dv", precision="bf16", return_stats=True)
+    loss.sum().backward()
+    assert _hip.stats_dict(stats)["n_neg"] == int(orc.negative_mask(sid).sum())
+    s_r = orc.bilinear_scores(x.double(), y.double(), w.double(), round_fn=orc.round_bf16)
+    sc = max(float(s_r.abs().max()), 1.0)
+    assert abs(float(loss) - float(orc.bound_from_matrix(s_r, sid, "dv"))) < 2e-3 * sc
+    o = orc.matrix_step(lambda a, c, ww: orc.bilinear_scores(a, c, ww), [x.double(), y.double(), w.double()], sid, "dv")
+    for got, ref in zip((xl.grad, yl.grad, critic.weight.grad), o["grads"]):
+        err = float((got.cpu().double() - ref).abs().max()) / float(ref.abs().max())
+        assert err < 6e-2, err
+
+
 @pytest.mark.parametrize("b,d,est,dup", [(4096, 512, "infonce", "random"), (1024, 768, "dv", "survey")])
 def test_concat_full_size_sampled_rows_vs_oracle(dev, b, d, est, dup):
     """BASELINE config 4 size (B=4096, d=512) and config 3 size (B=1024, d=768, the reference's own widths) with the
