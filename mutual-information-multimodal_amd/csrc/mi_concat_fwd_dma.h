@@ -46,12 +46,15 @@ __global__ __launch_bounds__(256 * NWN, 2) void concat_fwd_dma_kernel(
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const int wn = wave >> 2, wp = wave & 3;
   const int c = lane & 31, h = lane >> 5;
-  // XCD-aware tile order: XCD e owns the column tiles jt = e + 8 m and sweeps the row tiles with them, so its share of
-  // V (one eighth of it) stays in its L2 for the whole launch and U is read from HBM once per XCD.
+  // XCD-aware tile order: XCD e owns the column tiles jt = e + 8 m and takes them one at a time, sweeping all row tiles
+  // under each.  The workgroups resident on an XCD then share ONE V tile (128 KB) and differ in their U tiles (32 KB
+  // each): per workgroup only its U tile is new to the L2.  (Cycling through the XCD's 16 column tiles first kept 2 MB
+  // of V + 1 MB of W2 live beside the bit-image write stream and re-fetched V about twice per workgroup: 18.3 GB of
+  // fetches per launch at B = 4096, profiles/r1_d_pmc_traffic.json.)
   const int n_jt = (int)((b + kFwdTJ - 1) / kFwdTJ), n_it = (int)((b_rows + kFwdTI - 1) / kFwdTI);
   const int njx = (n_jt + 7) / 8;
-  int jt = (int)(blockIdx.x & 7) + 8 * (int)((blockIdx.x >> 3) % njx);
-  int it = (int)((blockIdx.x >> 3) / njx);
+  int jt = (int)(blockIdx.x & 7) + 8 * (int)((blockIdx.x >> 3) / n_it);
+  int it = (int)((blockIdx.x >> 3) % n_it);
   if (natural_order) {
     jt = (int)(blockIdx.x % (8 * njx));
     it = (int)(blockIdx.x / (8 * njx));
