@@ -76,6 +76,40 @@ def test_bound_edge_cases(dev):
         mi_critics.dv_bound_loss(lg, 7, dev)
 
 
+def test_c_abi_status_codes(dev):
+    """The C ABI reports misuse through its status codes and mi_last_error (include/mi_critic.h), never by crashing:
+    -1 bad argument, -2 unsupported shape, -3 workspace too small."""
+    from mutual_info_img_txt import _hip
+    lib = _hip.load()
+    st = _hip.stream_ptr()
+    lg = torch.randn(64, device=dev)
+    loss = torch.empty(1, device=dev)
+    stats = _hip.new_stats(dev)
+    ws = _hip.workspace(lib.mi_bound_workspace_bytes(64), dev)
+    assert lib.mi_bound_fwd(None, 64, 8, 0, loss.data_ptr(), stats.data_ptr(), ws.data_ptr(), ws.numel(), st) == -1
+    assert lib.mi_last_error()  # thread-local text
+    assert lib.mi_bound_fwd(lg.data_ptr(), 64, 8, 7, loss.data_ptr(), stats.data_ptr(), ws.data_ptr(), ws.numel(), st) == -1
+    assert lib.mi_bound_fwd(lg.data_ptr(), 64, 8, 0, loss.data_ptr(), stats.data_ptr(), ws.data_ptr(), 8, st) == -3
+    assert lib.mi_bound_fwd(lg.data_ptr(), 64, 8, 0, loss.data_ptr(), stats.data_ptr(), ws.data_ptr(), ws.numel(), st) == 0
+    # fused concat-MLP critic: hidden widths the kernels do not cover
+    b, d = 16, 8
+    x = torch.randn(b, d, device=dev)
+    sid = torch.arange(b, device=dev)
+    h1, h2 = 64, 384
+    w1, b1 = torch.randn(h1, 2 * d, device=dev), torch.randn(h1, device=dev)
+    w2, b2 = torch.randn(h2, h1, device=dev), torch.randn(h2, device=dev)
+    w3, b3 = torch.randn(h2, device=dev), torch.randn(1, device=dev)
+    scores = torch.empty(b, b, device=dev)
+    rec = torch.empty(8, device=dev)
+    big = _hip.workspace(1 << 24, dev)
+    rc = lib.mi_concat_mlp_fwd(x.data_ptr(), x.data_ptr(), w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(),
+                               w3.data_ptr(), b3.data_ptr(), sid.data_ptr(), sid.data_ptr(), b, b, 0, d, d, h1, h2, 0, 1, 1,
+                               loss.data_ptr(), stats.data_ptr(), rec.data_ptr(), scores.data_ptr(), big.data_ptr(),
+                               big.numel(), st)
+    assert rc == -2 and b"h2" in lib.mi_last_error()
+    torch.cuda.synchronize()
+
+
 # ------------------------------------------------------------------------------------------------ a1
 def test_pair_index_golden(dev, golden):
     from mutual_info_img_txt.main_utils import pair_index
