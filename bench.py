@@ -43,10 +43,11 @@ def parse_args():
     p.add_argument("--estimator", default="infonce", choices=["dv", "infonce"])
     p.add_argument("--precision", default="bf16", choices=["bf16", "f32"])
     p.add_argument("--graph", default="auto", choices=["auto", "on", "off"],
-                   help="replay the step from a hipGraph.  auto: single-GPU bilinear step only (eagerly that step is "
-                        "bound by the host's launch rate, not by the GPU); the concat-MLP step (52 ms of kernels) and "
-                        "multi-GPU runs stay eager -- capturing the concat sequence crashes inside capture_end on "
-                        "ROCm 7.2, which cannot be caught from Python")
+                   help="replay the step from hipGraphs.  auto: the bilinear step -- eagerly it is bound by the host's "
+                        "launch rate, not by the GPU: on one GPU the whole step is one graph; sharded over GPUs the two "
+                        "compute sections are graphs and the RCCL collectives stay eager between them.  The concat-MLP "
+                        "step (52 ms of kernels) stays eager: capturing it crashes inside capture_end on ROCm 7.2, "
+                        "which cannot be caught from Python")
     p.add_argument("--no-secondary", action="store_true")
     p.add_argument("--secondary-steps", type=int, default=5)
     p.add_argument("--no-cpu-baseline", action="store_true")
@@ -129,6 +130,8 @@ class Stepper:
         self.y.requires_grad_(True)
         self.args = args
         self.graph = None
+        self.staged = None
+        self.dist_mode = not (world == 1 and not os.environ.get("MI_BENCH_FORCE_DIST"))
         if world == 1 and not os.environ.get("MI_BENCH_FORCE_DIST"):
             self._loss = lambda: mi_critics.fused_mi_bound(self.x, self.y, self.sid, self.critic, args.estimator,
                                                            precision=args.precision)
@@ -169,8 +172,16 @@ class Stepper:
             self.loss.sum().backward()
         self.graph = g
 
+    def try_staged(self, group):
+        """Sharded step with its two compute sections replayed from hipGraphs and the collectives eager between them."""
+        from mutual_info_img_txt.distributed import GlobalBatchGraphStep
+        self.staged = GlobalBatchGraphStep(self.x.detach(), self.y.detach(), self.sid, self.params, self.args.estimator,
+                                           self.args.precision, critic=self.kind, group=group)
+
     def step(self):
-        if self.graph is not None:
+        if self.staged is not None:
+            self.loss = self.staged.step()
+        elif self.graph is not None:
             self.graph.replay()
         else:
             self.eager()
@@ -319,15 +330,20 @@ def main():
     def run(kind, steps, warmup):
         st = Stepper(kind, args, rank, world, device, group)
         graph_used = False
-        want_graph = args.graph == "on" or (args.graph == "auto" and kind == "bilinear" and world == 1)
+        want_graph = args.graph == "on" or (args.graph == "auto" and kind == "bilinear")
         if want_graph:
             try:
-                st.try_capture()
-                graph_used = True
+                if st.dist_mode:
+                    st.try_staged(group)
+                    graph_used = "staged"
+                else:
+                    st.try_capture()
+                    graph_used = True
             except Exception as e:  # capture is an optimisation, not a requirement
                 if args.graph == "on":
                     raise
                 st.graph = None
+                st.staged = None
                 torch.cuda.synchronize()
                 if rank == 0:
                     print(f"[bench] hipGraph capture unavailable ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
@@ -357,7 +373,9 @@ def main():
                                f"{args.critic} critic fwd+bwd, B_global={b}, d={d}",
                    "global_batch": b, "embed_dim": d, "critic": args.critic, "estimator": args.estimator,
                    "parallelism": f"row-block sharding x{world}, RCCL all-gather of text embeddings" if world > 1 else "single GPU",
-                   "hip_graph": graph_used},
+                   "hip_graph": bool(graph_used),
+                   "graph_mode": {True: "whole step", "staged": "compute sections; collectives eager between them",
+                                  False: "none"}[graph_used]},
         "loss": loss,
         "step_algorithmic_tflops": round(flops / (ms * 1e-3) / 1e12, 2),
         "step_frac_of_peak": round(flops / (ms * 1e-3) / 1e12 / (PEAK_TFLOPS[args.precision] * world), 5),

@@ -179,3 +179,79 @@ def global_batch_mi_bound(embedding_img, embedding_txt, study_id_codes, critic_p
                                             *critic_params)
     loss = loss if estimator == "dv" else loss.reshape(())
     return (loss, stats) if return_stats else loss
+
+
+class GlobalBatchGraphStep:
+    """Forward + backward of the global-batch bound for FIXED shapes and storage, with the two compute sections of a
+    step replayed from hipGraphs and the collectives issued eagerly between them:
+
+        all-gather Y, ids | graph 1: local forward -> partial record | all-gather records |
+        graph 2: rank-ordered merge + local backward | reduce-scatter dY, all-reduce d(params)
+
+    Why: at global batch 4096 a rank's kernels take tens of microseconds, and launching them one by one from Python
+    (plus an autograd graph) costs several times that.  The graphs hold exactly the C-ABI calls of
+    ``GlobalBatchCriticFn``; no collective is captured (RCCL calls stay ordinary stream work between two replays).
+
+    ``x``, ``y`` [B/G, d], ``sid`` int64 [B/G] and ``params`` are read in place on every ``step()``: update their
+    contents (``copy_``), not the objects.  ``step()`` returns the loss ([1]); gradients are in ``grad_x``, ``grad_y``,
+    ``grad_params`` (overwritten by every step)."""
+
+    def __init__(self, x, y, sid, params: Sequence[torch.Tensor], estimator: str = "infonce", precision: str = "bf16",
+                 critic: str = "bilinear", group=None, ops=None):
+        from .mi_critics import _estimator_code, _precision_code
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        self.ops = ops if ops is not None else {"bilinear": HipBilinearOps, "concat_mlp": HipConcatMlpOps}[critic]()
+        self.est, self.prec = _estimator_code(estimator), _precision_code(precision)
+        self.x, self.y, self.sid = x.detach(), y.detach(), sid
+        self.params = [p.detach() for p in params]
+        for t in (self.x, self.y, self.sid, *self.params):
+            if not t.is_contiguous():
+                raise ValueError("GlobalBatchGraphStep needs contiguous tensors (they are read in place)")
+        br = x.shape[0]
+        dev = x.device
+        self.y_all = torch.empty((self.world * br,) + tuple(y.shape[1:]), dtype=y.dtype, device=dev)
+        self.sid_all = torch.empty(self.world * br, dtype=sid.dtype, device=dev)
+        self.records = torch.empty(self.world, _hip.RECORD_FLOATS, dtype=torch.float32, device=dev)
+        self.grad_out = torch.ones(1, dtype=torch.float32, device=dev)
+        self._gather_inputs()
+        torch.cuda.synchronize()
+        # warm-up on a side stream (module loading, attribute calls), then capture
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            self._forward()
+            self._merge_backward()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.graph_fwd = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph_fwd):
+            self._forward()
+        # the record gathered from every rank must exist before the second capture reads it
+        dist.all_gather_into_tensor(self.records, self.record.reshape(1, -1), group=self.group)
+        self.graph_bwd = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph_bwd, pool=self.graph_fwd.pool()):
+            self._merge_backward()
+
+    def _gather_inputs(self):
+        dist.all_gather_into_tensor(self.y_all, self.y, group=self.group)
+        dist.all_gather_into_tensor(self.sid_all, self.sid, group=self.group)
+
+    def _forward(self):
+        self.record, self.saved = self.ops.forward(self.x, self.y_all, self.params, self.sid, self.sid_all,
+                                                   self.rank * self.x.shape[0], self.est, self.prec, True)
+
+    def _merge_backward(self):
+        self.loss, self.stats = self.ops.merge(self.records, self.world * self.x.shape[0], self.est)
+        self.grad_x, self.grad_y_partial, self.grad_params = self.ops.backward(self.saved, self.stats, self.grad_out)
+
+    def step(self):
+        self._gather_inputs()
+        self.graph_fwd.replay()
+        dist.all_gather_into_tensor(self.records, self.record.reshape(1, -1), group=self.group)
+        self.graph_bwd.replay()
+        self.grad_y = _reduce_scatter_rows(self.grad_y_partial, self.group)
+        for g in self.grad_params:
+            dist.all_reduce(g, group=self.group)
+        return self.loss

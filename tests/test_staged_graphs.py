@@ -1,0 +1,42 @@
+"""GlobalBatchGraphStep (hipGraph-replayed compute sections around eager collectives) against the autograd path of
+global_batch_mi_bound, on one GPU with a one-rank RCCL group (the exchange logic itself is covered by the two-rank gloo
+test in test_distributed_cpu.py)."""
+import pytest
+import torch
+
+
+@pytest.mark.gpu
+def test_staged_graph_step_matches_autograd_path():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import torch.distributed as dist
+    from mutual_info_img_txt.distributed import GlobalBatchGraphStep, global_batch_mi_bound
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29547", rank=0, world_size=1, device_id=dev)
+    try:
+        gen = torch.Generator().manual_seed(9)
+        b, d = 512, 128
+        x = torch.randn(b, d, generator=gen).to(dev)
+        y = torch.randn(b, d, generator=gen).to(dev)
+        w = (torch.randn(d, d, generator=gen) * 0.1).to(dev)
+        sid = torch.randint(0, b // 2, (b,), generator=gen).to(dev)
+        stepper = GlobalBatchGraphStep(x, y, sid, [w], "infonce", "bf16", critic="bilinear", group=dist.group.WORLD)
+        for trial in range(3):  # new contents, same storage
+            if trial:
+                x.copy_(torch.randn(b, d, generator=gen))
+                y.copy_(torch.randn(b, d, generator=gen))
+                w.copy_(torch.randn(d, d, generator=gen) * 0.1)
+            loss = stepper.step()
+            xl, yl, wl = (t.clone().requires_grad_(True) for t in (x, y, w))
+            ref = global_batch_mi_bound(xl, yl, sid, [wl], "infonce", "bf16", critic="bilinear", group=dist.group.WORLD)
+            ref.sum().backward()
+            torch.cuda.synchronize()
+            assert float(loss) == float(ref)  # same kernels, same order: bit-identical
+            assert torch.equal(stepper.grad_x, xl.grad) and torch.equal(stepper.grad_y, yl.grad)
+            assert torch.equal(stepper.grad_params[0], wl.grad)
+    finally:
+        if created:
+            dist.destroy_process_group()
