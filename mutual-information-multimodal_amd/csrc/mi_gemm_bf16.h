@@ -1154,7 +1154,42 @@ struct CvtJob {
 struct CvtJobs {
   CvtJob j[3];
 };
+// 64 x 64 tiles, 16-byte loads and 8-byte stores in both orientations (R % 4 == 0 and C % 4 == 0; 16-byte aligned
+// bases): 34 MB move per bilinear forward, ~10 us with 4-byte accesses on 32 x 32 tiles.
 static __global__ __launch_bounds__(256) void cvt_transpose3_kernel(CvtJobs jobs) {
+  __shared__ float tile[64][65];
+  const CvtJob& J = jobs.j[blockIdx.z];
+  const int64_t r0 = (int64_t)blockIdx.y * 64, c0 = (int64_t)blockIdx.x * 64;
+  if (r0 >= J.R || c0 >= J.C) return;
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;  // 16 column quads x 16 rows per pass
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int rl = ty + 16 * q;
+    const int64_t r = r0 + rl, c = c0 + 4 * tx;
+    f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (r < J.R && c < J.C) v = *reinterpret_cast<const f32x4*>(J.in + r * J.C + c);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) tile[rl][4 * tx + e] = v[e];
+    if (J.out_rm && r < J.R && c < J.C) {
+      const bf16x4 o = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+      *reinterpret_cast<bf16x4*>(J.out_rm + r * J.C + c) = o;
+    }
+  }
+  if (!J.out_t) return;
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int cl = ty + 16 * q;
+    const int64_t c = c0 + cl, r = r0 + 4 * tx;
+    if (c < J.C && r < J.R) {
+      const bf16x4 o = {(bf16_t)tile[4 * tx][cl], (bf16_t)tile[4 * tx + 1][cl], (bf16_t)tile[4 * tx + 2][cl],
+                        (bf16_t)tile[4 * tx + 3][cl]};
+      *reinterpret_cast<bf16x4*>(J.out_t + c * J.R + r) = o;
+    }
+  }
+}
+// any shape: 32 x 32 tiles, element accesses
+static __global__ __launch_bounds__(256) void cvt_transpose3_generic_kernel(CvtJobs jobs) {
   __shared__ float tile[32][33];
   const CvtJob& J = jobs.j[blockIdx.z];
   const int64_t r0 = (int64_t)blockIdx.y * 32, c0 = (int64_t)blockIdx.x * 32;
@@ -1177,14 +1212,23 @@ static __global__ __launch_bounds__(256) void cvt_transpose3_kernel(CvtJobs jobs
 }
 static inline int launch_cvt_transpose3(const CvtJobs& jobs, hipStream_t st, const char* what) {
   int64_t rmax = 0, cmax = 0;
+  bool vec = true;
   for (int q = 0; q < 3; ++q) {
-    if (jobs.j[q].R > rmax) rmax = jobs.j[q].R;
-    if (jobs.j[q].C > cmax) cmax = jobs.j[q].C;
+    const CvtJob& J = jobs.j[q];
+    if (J.R > rmax) rmax = J.R;
+    if (J.C > cmax) cmax = J.C;
+    vec = vec && J.R % 4 == 0 && J.C % 4 == 0 && (uintptr_t)J.in % 16 == 0 && (uintptr_t)J.out_rm % 8 == 0 &&
+          (uintptr_t)J.out_t % 8 == 0;
   }
-  dim3 grid((unsigned)((cmax + 31) / 32), (unsigned)((rmax + 31) / 32), 3);
   {
     ProfScope prof_(what, st);
-    hipLaunchKernelGGL(cvt_transpose3_kernel, grid, dim3(256), 0, st, jobs);
+    if (vec) {
+      dim3 grid((unsigned)((cmax + 63) / 64), (unsigned)((rmax + 63) / 64), 3);
+      hipLaunchKernelGGL(cvt_transpose3_kernel, grid, dim3(256), 0, st, jobs);
+    } else {
+      dim3 grid((unsigned)((cmax + 31) / 32), (unsigned)((rmax + 31) / 32), 3);
+      hipLaunchKernelGGL(cvt_transpose3_generic_kernel, grid, dim3(256), 0, st, jobs);
+    }
   }
   MI_LAUNCH_CHECK(what);
   return MI_OK;
