@@ -935,10 +935,14 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_big_kernel(GemmBf16Args args
   }
 
   const int64_t nt = P.k / kG2KT;
+  MI_STAMP(0);
   if (nt > 0) issue_tile(0, 0);
   __syncthreads();
+  MI_STAMP(1);
   for (int64_t t = 0; t < nt; ++t) {
     const int buf = (int)(t & 1);
+    if (t == nt / 4) MI_STAMP(2);
+    if (t == (3 * nt) / 4) MI_STAMP(3);
     if (t + 1 < nt) issue_tile(t + 1, buf ^ 1);
     const char* at = smem_raw + buf * 65536;
     const char* bt = at + 32768;
@@ -967,10 +971,13 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_big_kernel(GemmBf16Args args
     __syncthreads();
   }
   const int64_t mb = m0 + wm * 128, nb = n0 + wn * 64;
+  MI_STAMP(4);
   if constexpr (Epi::kReducesPartial) {
     __shared__ Partial scratch[8];
     Partial p = epi.lane_partial(acc[0], mb, nb, P.m, P.n);
+    MI_STAMP(6);
     const Partial q = epi.lane_partial(acc[1], mb + 64, nb, P.m, P.n);
+    MI_STAMP(7);
     lse_merge(p.m, p.s, q.m, q.s);
     p.pos += q.pos;
     p.cnt += q.cnt;
@@ -979,8 +986,11 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_big_kernel(GemmBf16Args args
   } else {
     char* lds = smem_raw + wave * kEpiLdsPerWave;
     epi(acc[0], mb, nb, P.m, P.n, 0, 0, lds);
+    MI_STAMP(6);
     epi(acc[1], mb + 64, nb, P.m, P.n, 0, 0, lds);
+    MI_STAMP(7);
   }
+  MI_STAMP(5);
 }
 
 constexpr size_t kG2SmemBig = 2 * 2 * 32768;  // 131,072 bytes

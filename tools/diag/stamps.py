@@ -42,3 +42,6 @@ for i, n in enumerate(names):
     print(f"{n:24s} median {np.median(dlt):9.0f}  p10 {np.percentile(dlt,10):9.0f}  p90 {np.percentile(dlt,90):9.0f} cycles")
 print(f"start skew (entry - first entry): median {np.median(s[:,0]-t0):.0f} max {np.max(s[:,0]-t0):.0f}")
 print(f"whole WG: median {np.median(s[:,5]-s[:,0]):.0f}; kernel span {s[:,5].max()-t0} ticks of s_memtime")
+if s[:, 6].any():
+    print("epilogue halves (slots 4 -> 6 -> 7 -> 5):",
+          f"first half {np.median(s[:,6]-s[:,4]):.0f}, second half {np.median(s[:,7]-s[:,6]):.0f}, tail {np.median(s[:,5]-s[:,7]):.0f} cycles")
