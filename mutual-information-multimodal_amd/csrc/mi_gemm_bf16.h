@@ -267,33 +267,42 @@ struct EpiScoreLse2 {
     float mx = MI_NEG_INF, pos = 0.0f;
     unsigned cnt = 0;
     if (!scores && mb + 64 <= M && nb + 64 <= N) {
-      // interior tile, no score output: branch-free.  A pair is a negative iff the study ids differ (the diagonal
-      // pairs a sample with itself, so it never counts as one); the diagonal needs a look only where the tile's row
-      // and column ranges meet.
+      // interior tile, no score output.  A pair is a negative iff the study ids differ (the diagonal pairs a sample
+      // with itself, so it never counts as one).  Per element: one 64-bit compare, one select, one max; the negative
+      // count comes from the compare's lane mask on the scalar unit (s_bcnt1), not from a per-lane add.
       const int64_t dlo = row_offset + mb - nb;  // global row - column of the tile's (0, 0)
-      const bool has_diag = dlo > -64 && dlo < 64;
+      if (__builtin_amdgcn_readfirstlane((int)(dlo > -64 && dlo < 64))) {
+        // the tile's row and column ranges meet: pick the positives up first (one tile in 16 at B = 4096)
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+          for (int tn = 0; tn < 2; ++tn) {
+            const int d = (int)(tn * 32 + col_l - tm * 32 - 4 * half - dlo);  // row offset in the 32-row group
+#pragma unroll
+            for (int r = 0; r < 16; ++r) pos += (d == (r & 3) + 8 * (r >> 2)) ? acc[tm][tn][r] : 0.0f;
+          }
+      }
+      unsigned cnt_wave = 0;  // wave-uniform
 #pragma unroll
       for (int tm = 0; tm < 2; ++tm) {
         int64_t sr[16];
+        const int64_t* srp = sid_rows + mb + tm * 32 + 4 * half;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) sr[r] = sid_rows[mb + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half];
+        for (int r = 0; r < 16; ++r) sr[r] = srp[(r & 3) + 8 * (r >> 2)];
 #pragma unroll
         for (int tn = 0; tn < 2; ++tn) {
           const int64_t sc = sid_cols[nb + tn * 32 + col_l];
-          // the element is on the diagonal iff its row offset inside the 32-row group equals d
-          const int d = has_diag ? (int)(tn * 32 + col_l - tm * 32 - 4 * half - dlo) : -1;
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
-            const float v = acc[tm][tn][r];
             const bool neg = sr[r] != sc;
-            if (has_diag) pos += (d == (r & 3) + 8 * (r >> 2)) ? v : 0.0f;
-            const float vn = neg ? v : MI_NEG_INF;
+            cnt_wave += (unsigned)__popcll(__ballot(neg));
+            const float vn = neg ? acc[tm][tn][r] : MI_NEG_INF;
             mx = fmaxf(mx, vn);
-            cnt += neg ? 1u : 0u;
             acc[tm][tn][r] = vn;
           }
         }
       }
+      cnt = lane == 0 ? cnt_wave : 0u;
     } else {
 #pragma unroll
       for (int tm = 0; tm < 2; ++tm)
@@ -322,13 +331,16 @@ struct EpiScoreLse2 {
         }
     }
     float s = 0.0f;
-    if (cnt > 0) {
+    if (mx > MI_NEG_INF) {
+      // exp(v - mx) = 2^(v log2e - mx log2e): one fma and one v_exp_f32 per element (v = -inf gives 0)
+      constexpr float kLog2e = 1.4426950408889634f;
+      const float off = -mx * kLog2e;
 #pragma unroll
       for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
         for (int tn = 0; tn < 2; ++tn)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) s += __expf(acc[tm][tn][r] - mx);
+          for (int r = 0; r < 16; ++r) s += __builtin_amdgcn_exp2f(__builtin_fmaf(acc[tm][tn][r], kLog2e, off));
     }
     return Partial{mx, s, pos, cnt};
   }
@@ -361,26 +373,37 @@ struct EpiGradScore2 {
     const int col_l = lane & 31, half = lane >> 5;
     const bool staged = (M % 8 == 0) && (N % 8 == 0);
     if (staged && mb + 64 <= M && nb + 64 <= N) {
-      // interior tile: branch-free (see EpiScoreLse2::lane_partial)
+      // interior tile (see EpiScoreLse2::lane_partial): G = go * exp(S - lse) where the study ids differ, else 0;
+      // go * exp(v - lse) = go * 2^(v log2e - lse log2e), one fma + v_exp_f32 + mul (bf16 output: native exp is ample)
       const int64_t dlo = row_offset + mb - nb;
-      const bool has_diag = dlo > -64 && dlo < 64;
+      constexpr float kLog2e = 1.4426950408889634f;
+      const float off = -lse * kLog2e;
 #pragma unroll
       for (int tm = 0; tm < 2; ++tm) {
         int64_t sr[16];
+        const int64_t* srp = sid_rows + mb + tm * 32 + 4 * half;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) sr[r] = sid_rows[mb + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half];
+        for (int r = 0; r < 16; ++r) sr[r] = srp[(r & 3) + 8 * (r >> 2)];
 #pragma unroll
         for (int tn = 0; tn < 2; ++tn) {
           const int64_t sc = sid_cols[nb + tn * 32 + col_l];
-          const int d = has_diag ? (int)(tn * 32 + col_l - tm * 32 - 4 * half - dlo) : -1;
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
-            const float e = go * __expf(acc[tm][tn][r] - lse);  // bf16 output: native exp is ample
-            float gv = sr[r] != sc ? e : 0.0f;
-            if (has_diag) gv = (d == (r & 3) + 8 * (r >> 2)) ? gpos : gv;
-            acc[tm][tn][r] = gv;
+            const float e = go * __builtin_amdgcn_exp2f(__builtin_fmaf(acc[tm][tn][r], kLog2e, off));
+            acc[tm][tn][r] = sr[r] != sc ? e : 0.0f;
           }
         }
+      }
+      if (__builtin_amdgcn_readfirstlane((int)(dlo > -64 && dlo < 64))) {
+        // the tile's row and column ranges meet: the positives get -go / n_pos (one tile in 16 at B = 4096)
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+          for (int tn = 0; tn < 2; ++tn) {
+            const int d = (int)(tn * 32 + col_l - tm * 32 - 4 * half - dlo);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[tm][tn][r] = (d == (r & 3) + 8 * (r >> 2)) ? gpos : acc[tm][tn][r];
+          }
       }
     } else {
 #pragma unroll
