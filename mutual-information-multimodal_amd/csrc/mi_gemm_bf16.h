@@ -1,12 +1,17 @@
-// bf16 MFMA GEMM for K-contiguous bf16 operands (the fast path of the bilinear critic):
+// bf16 MFMA GEMMs for K-contiguous bf16 operands (the fast path of the bilinear critic):
 //   C[m, n] = sum_k A[m][k] * B[n][k]        A: [M][lda], B: [N][ldb], bf16, 16-byte aligned rows, K % 8 == 0
-// Up to two independent problems per launch (blockIdx.z selects; fills the chip when one problem has only 128 tiles)
-// and split-K by blockIdx.z for a single problem (partial sums go to slabs, reduced in a fixed order afterwards).
+// Up to two independent problems per launch and split-K (partial sums go to slabs, reduced in a fixed order afterwards);
+// the epilogue functors (store in several formats, masked log-sum-exp partial, dL/dS in both orientations) are shared.
 //
-// 128 x 128 x 64 tiles, 256 threads = 4 waves (2 x 2), each 64 x 64 = 2 x 2 v_mfma_f32_32x32x16_bf16 tiles.
-// Global -> registers -> LDS staging, double-buffered LDS (one barrier per K tile): the next tile's 16-byte loads are
-// issued before the current tile's 16 MFMAs and written to the other buffer after them (guide T14).  LDS rows are
-// padded to 144 bytes, which makes every ds_read_b128 fragment read conflict-free.  72 KB of LDS -> 2 workgroups / CU.
+// Four kernels, picked per launch by launch_gemm_bf16 / launch_gemm_bf16_flat (measurements: profiles/README.md):
+//   gemm_bf16_kernel       128 x 128 x 64 tile, 4 waves, global -> registers -> LDS with 144-byte padded rows.  Any K % 8
+//                          == 0 shape; the fallback when K is not a multiple of 64.
+//   gemm_bf16_glds_kernel  same tile, operands L2 -> LDS by global_load_lds_dwordx4 (XOR-swizzled image), two workgroups
+//                          per CU.  The short products with few tiles: T = X W, and dW | dX as one flat launch.
+//   gemm_bf16_big_kernel   256 x 256 x 64 tile, 8 waves, one workgroup per CU.  The K = d products over the B x B
+//                          matrix (score + LSE, G): half the LDS-DMA bytes per flop of the 128 x 128 tile.
+//   gemm_bf16_pipe_kernel  128 x 128 x 64 tile, 8 waves in two groups half an iteration apart (ping-pong), three LDS
+//                          stages, counted s_waitcnt vmcnt.  The long-K pair dT = G Y | dY = G^T T.
 #pragma once
 #include "mi_common.h"
 #include "mi_gemm.h"
@@ -682,7 +687,6 @@ struct PipeCfg {
   __device__ static __forceinline__ int swz(int row) { return KT == 64 ? (row >> 1) & 7 : (row >> 2) & 3; }
 };
 using PipeCfg128 = PipeCfg<128, 128, 64, 2, 2, 2>;
-using PipeCfg256 = PipeCfg<256, 256, 32, 2, 4, 1>;
 
 template <int N>
 __device__ __forceinline__ void wait_vmcnt_barrier() {
@@ -738,8 +742,6 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_pipe_kernel(GemmBf16Args arg
     if (g >= lim) g = lim - 1;  // clamped rows only feed outputs the epilogue drops
 #ifdef MI_STAMPS
     if (args.exp_mode == 95) g &= 255;               // diagnostic: every tile reads the same 256 rows (L2-resident)
-    if (args.exp_mode == 94 && !is_b) g &= 255;      // ... only A
-    if (args.exp_mode == 93 && is_b) g &= 127;       // ... only B
 #endif
     const bf16_t* base = is_b ? P.b + g * P.ldb : P.a + g * P.lda;
     src[i] = reinterpret_cast<const char*>(base + kbeg) + chunk * 16;
