@@ -655,18 +655,19 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_glds_kernel(GemmBf16Args arg
 }
 
 // ------------------------------------------------------------------------------------------------ pipelined kernel
-// In-kernel s_memtime stamps of the double-buffered kernels above (profiles/README.md, r1_c): a 128 x 128 x 64 step
-// took ~1,800 cycles against 512 cycles of MFMA per SIMD, and it took that long TWICE over -- with the LDS-DMA removed
-// (one wave per SIMD exposes every ds_read latency) and with the MFMAs removed (one K tile in flight per workgroup:
-// ~2,200 cycles of load latency per tile).  This kernel addresses both:
-//   * three LDS stages, two K tiles in flight: the wait before a tile is a counted s_waitcnt vmcnt(pieces of ONE tile),
-//     followed by a bare s_barrier (hipcc's __syncthreads would drain vmcnt to 0);
-//   * always 8 waves = two per SIMD, so one wave's fragment waits overlap the other's MFMAs.
-// Two shapes:
-//   128 x 128 tile, K tile 64, waves 2 x 2 x 2 K groups (waves 4..7 take the second half of every K tile; the two
-//     partial accumulators are added through LDS before the epilogue)           -- long-K problems with few tiles
-//   256 x 256 tile, K tile 32, waves 2 x 4, each 128 x 64                      -- the K = d problems over B x B
-// A stage is 32 KB either way (96 KB of LDS, one workgroup per CU); every wave issues 4 LDS-DMA pieces per K tile.
+// In-kernel s_memtime stamps of the double-buffered kernels above (profiles/README.md): a 128 x 128 x 64 step took
+// ~1,800 cycles against 512 cycles of MFMA per SIMD.  The time goes to ISSUING the LDS-DMA pieces (a wave is held
+// ~180 cycles per 1 KB piece while eight waves issue) and, behind one barrier per K tile, both waves of a SIMD sit in
+// that phase together and then compete for the MFMA pipe together.  This kernel:
+//   * runs 8 waves as two groups (one wave per SIMD each) half an iteration apart: the memory phase of one group
+//     (fragment reads, LDS-DMA issue, wait) lies under the MFMA phase of the other, a barrier ends every phase;
+//   * keeps three LDS stages, two K tiles in flight: the wait is a counted s_waitcnt vmcnt(pieces of ONE tile) followed
+//     by a bare s_barrier (hipcc's __syncthreads would drain vmcnt to 0).
+// Instantiated shape: 128 x 128 tile, K tile 64, waves 2 x 2 x 2 K groups (waves 4..7 take the second half of every K
+// tile; the two partial accumulators are added through LDS before the epilogue).  The configuration struct also
+// admits a 256 x 256 tile with 32-deep K tiles (waves 2 x 4, each 128 x 64); on the K = d products it measured slower
+// than gemm_bf16_big_kernel (score 26.8 -> 29.5 us) and is not instantiated.
+// A stage is 32 KB (96 KB of LDS, one workgroup per CU); every wave issues 4 LDS-DMA pieces per K tile.
 // Swizzle: chunk c (16 bytes) of row r sits at chunk position c ^ f(r), f(r) = (r >> 1) & 7 for 128-byte rows and
 // (r >> 2) & 3 for 64-byte rows: conflict-free for the lane groups ds_read_b128 serves per LDS cycle.
 template <int BM_, int BN_, int KT_, int WM_, int WN_, int KG_>
