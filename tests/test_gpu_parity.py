@@ -482,14 +482,17 @@ def test_concat_bf16_backward_vs_rounded_oracle(dev, b, dx, dy, h1, h2, dup):
 
 
 # ------------------------------------------------------------------------------------------------ row-block sharding
-@pytest.mark.parametrize("critic", ["bilinear", "concat_mlp"])
-@pytest.mark.parametrize("precision", ["f32", "bf16"])
-def test_row_block_sharding_equals_full_batch(dev, critic, precision):
+@pytest.mark.parametrize("critic,precision,b,d,G", [
+    ("bilinear", "f32", 192, 64, 3), ("bilinear", "bf16", 192, 64, 3), ("concat_mlp", "f32", 192, 64, 3),
+    ("concat_mlp", "bf16", 192, 64, 3),
+    # BASELINE config 4's sharding (8 ranks x 512 rows of a 4096 batch) and a 4-rank split: these row-block shapes take
+    # the 128-tile score / G kernels and the two-problem long-K kernel with problems of different K (B against B/G)
+    ("bilinear", "bf16", 4096, 512, 8), ("bilinear", "bf16", 2048, 256, 4)])
+def test_row_block_sharding_equals_full_batch(dev, critic, precision, b, d, G):
     """What each rank of an N-GPU run computes (its row block against all columns), emulated on one GPU:
     merged statistics and summed gradients of G row blocks must equal the single-block result."""
     from mutual_info_img_txt import _hip
     from mutual_info_img_txt.distributed import HipBilinearOps, HipConcatMlpOps
-    b, d, G = 192, 64, 3
     x, y, sid, params = orc.synthetic_case(b, d, d, h1=128, h2=256, salt=5, dup=True)
     codes = torch.from_numpy(orc.sid_to_int(sid)).to(dev)
     if critic == "bilinear":
@@ -522,7 +525,7 @@ def test_row_block_sharding_equals_full_batch(dev, critic, precision):
     lg, sg, gxg, gyg, gpg = run(G)
     assert s1["n_neg"] == sg["n_neg"] and s1["n_pos"] == sg["n_pos"] == b
     assert abs(float(l1) - float(lg)) < 2e-6 * max(1.0, abs(float(l1)))
-    tol = 2e-5 if precision == "f32" else 2e-3
+    tol = 2e-5 if precision == "f32" else (2e-3 if b < 1024 else 4e-3)  # bf16: dT is rounded per row block
     for a, c in [(gx1, gxg), (gy1, gyg)] + list(zip(gp1, gpg)):
         scale = max(float(a.abs().max()), 1e-12)
         assert float((a - c).abs().max()) <= tol * scale + 1e-7
