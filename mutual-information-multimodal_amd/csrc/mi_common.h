@@ -93,7 +93,9 @@ __device__ __forceinline__ void lse_push(float& m, float& s, float x) {
     s += expf(x - m);
   }
 }
-// (m, s) <- (m, s) (+) (m2, s2); safe for empty sets (m == -inf, s == 0)
+// (m, s) <- (m, s) (+) (m2, s2); safe for empty sets (m == -inf, s == 0).  FAST: hardware exponential (v_exp_f32) for
+// the bf16-operand paths, whose scores already carry ~1e-2 relative error.
+template <bool FAST = false>
 __device__ __forceinline__ void lse_merge(float& m, float& s, float m2, float s2) {
   float mm = fmaxf(m, m2);
   if (mm == MI_NEG_INF) {
@@ -101,7 +103,8 @@ __device__ __forceinline__ void lse_merge(float& m, float& s, float m2, float s2
     s = 0.0f;
     return;
   }
-  s = s * expf(m - mm) + s2 * expf(m2 - mm);
+  if (FAST) s = s * __expf(m - mm) + s2 * __expf(m2 - mm);
+  else s = s * expf(m - mm) + s2 * expf(m2 - mm);
   m = mm;
 }
 
@@ -115,20 +118,21 @@ __device__ __forceinline__ unsigned wave_sum_u(unsigned v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
   return v;
 }
+template <bool FAST = false>
 __device__ __forceinline__ void wave_lse(float& m, float& s) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
     float m2 = __shfl_xor(m, o);
     float s2 = __shfl_xor(s, o);
-    lse_merge(m, s, m2, s2);
+    lse_merge<FAST>(m, s, m2, s2);
   }
 }
 
 // Reduce a Partial over a workgroup of NWAVES*64 threads; result valid in thread 0.  `scratch` holds
 // NWAVES Partials.  All threads must call.
-template <int NWAVES>
+template <int NWAVES, bool FAST = false>
 __device__ __forceinline__ Partial block_reduce_partial(Partial p, Partial* scratch) {
-  wave_lse(p.m, p.s);
+  wave_lse<FAST>(p.m, p.s);
   p.pos = wave_sum(p.pos);
   p.cnt = wave_sum_u(p.cnt);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -137,7 +141,7 @@ __device__ __forceinline__ Partial block_reduce_partial(Partial p, Partial* scra
   if (threadIdx.x == 0) {
     Partial r = scratch[0];
     for (int w = 1; w < NWAVES; ++w) {
-      lse_merge(r.m, r.s, scratch[w].m, scratch[w].s);
+      lse_merge<FAST>(r.m, r.s, scratch[w].m, scratch[w].s);
       r.pos += scratch[w].pos;
       r.cnt += scratch[w].cnt;
     }

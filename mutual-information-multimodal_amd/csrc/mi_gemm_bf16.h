@@ -353,7 +353,7 @@ struct EpiScoreLse2 {
                                              int, char*) const {
     __shared__ Partial scratch[4];
     Partial p = lane_partial(acc, mb, nb, M, N);
-    p = block_reduce_partial<4>(p, scratch);
+    p = block_reduce_partial<4, true>(p, scratch);
     if (threadIdx.x == 0) partials[(int64_t)blockIdx.y * gridDim.x + blockIdx.x] = p;
   }
 };
@@ -876,11 +876,11 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_pipe_kernel(GemmBf16Args arg
     Partial p = epi.lane_partial(acc[0], mb, nb, P.m, P.n);
     if constexpr (Cfg::TM == 4) {
       const Partial q = epi.lane_partial(acc[Cfg::TM / 2 - 1], mb + 64, nb, P.m, P.n);
-      lse_merge(p.m, p.s, q.m, q.s);
+      lse_merge<true>(p.m, p.s, q.m, q.s);
       p.pos += q.pos;
       p.cnt += q.cnt;
     }
-    p = block_reduce_partial<8>(p, scratch);
+    p = block_reduce_partial<8, true>(p, scratch);
     if (threadIdx.x == 0) epi.partials[(int64_t)blockIdx.y * gridDim.x + blockIdx.x] = p;
   } else {
     epi(acc[0], mb, nb, P.m, P.n, prob, zsplit, lds);
@@ -1004,10 +1004,10 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_big_kernel(GemmBf16Args args
     MI_STAMP(6);
     const Partial q = epi.lane_partial(acc[1], mb + 64, nb, P.m, P.n);
     MI_STAMP(7);
-    lse_merge(p.m, p.s, q.m, q.s);
+    lse_merge<true>(p.m, p.s, q.m, q.s);
     p.pos += q.pos;
     p.cnt += q.cnt;
-    p = block_reduce_partial<8>(p, scratch);
+    p = block_reduce_partial<8, true>(p, scratch);
     if (threadIdx.x == 0) epi.partials[(int64_t)blockIdx.y * gridDim.x + blockIdx.x] = p;
   } else {
     char* lds = smem_raw + wave * kEpiLdsPerWave;
