@@ -103,7 +103,7 @@ def kernel_flops(name, br, b, d_img, d_txt, h1=1024, h2=512):
             return 4.0 * br * b * d_txt
         if any(t in name for t in ("score+LSE", "bilinear G", "dT = G Y", "dY = G^T T")):
             return 2.0 * br * b * d_txt
-        if "prep" in name:
+        if "prep" in name or "slabs" in name:
             return 0.0
         return 2.0 * br * d_img * d_txt
     if name in ("concat_fwd_kernel", "concat_bwd_duv_kernel", "concat_bwd_dw2_kernel"):

@@ -30,6 +30,10 @@ struct BilinearPlan {
   float* dw_slab;
   int dw_splits;
   int64_t dw_kchunk;
+  // row blocks of a sharded batch (b_rows < b): dT = G Y has few output tiles and a long K; split K into slabs
+  float* dt_slab;
+  int dt_splits;
+  int64_t dt_kchunk;
   size_t bytes;
 };
 
@@ -70,6 +74,17 @@ static BilinearPlan plan_bilinear(Workspace& ws, int64_t br, int64_t b, int64_t 
   p.dw_splits = (int)splits;
   p.dw_kchunk = kchunk;
   p.dw_slab = ws.take<float>(splits * dx * dy);
+  {
+    const int64_t t0 = ((br + kTile - 1) / kTile) * ((dy + kTile - 1) / kTile);
+    int64_t sp = br < b ? (128 + t0 - 1) / t0 : 1;
+    if (sp > 16) sp = 16;
+    int64_t kc = (b + sp - 1) / sp;
+    kc = (kc + kG2KT - 1) / kG2KT * kG2KT;
+    sp = (b + kc - 1) / kc;
+    p.dt_splits = (int)sp;
+    p.dt_kchunk = kc;
+    p.dt_slab = sp > 1 ? ws.take<float>(sp * br * dy) : nullptr;
+  }
   p.bytes = ws.off;
   return p;
 }
@@ -130,8 +145,30 @@ static int bilinear_bwd_fast(const int64_t* sid_rows, const int64_t* sid_cols, i
   EpiStoreMulti e2{};
   e2.out[0] = EpiOut{nullptr, 0, 0, p.dtb, dy, p.dttb, br};
   e2.out[1] = EpiOut{grad_y, dy, 0, nullptr, 0, nullptr, 0};
-  rc = launch_gemm_bf16(two, 1, e2, st, "bilinear dT = G Y | dY = G^T T");
-  if (rc) return rc;
+  bool split_done = false;
+  if (p.dt_splits > 1) {
+    // sharded row block: dT partial sums over K chunks into fp32 slabs, beside dY; then one pass that adds the slabs and
+    // writes the two bf16 orientations of dT
+    EpiStoreMulti es{};
+    es.out[0] = EpiOut{p.dt_slab, dy, br * dy, nullptr, 0, nullptr, 0};
+    es.out[1] = e2.out[1];
+    const int sp[2] = {p.dt_splits, 1};
+    const int64_t ch[2] = {p.dt_kchunk, br};
+    rc = launch_gemm_bf16_flat(two, sp, ch, es, st, "bilinear dT = G Y | dY = G^T T");
+    if (rc == MI_OK) {
+      CvtJobs jobs{};
+      jobs.j[0] = CvtJob{p.dt_slab, br, dy, p.dtb, p.dttb, p.dt_splits, br * dy};
+      rc = launch_cvt_transpose3(jobs, st, "bilinear dT slabs -> bf16");
+      if (rc) return rc;
+      split_done = true;
+    } else if (rc != MI_EINVAL) {
+      return rc;
+    }
+  }
+  if (!split_done) {
+    rc = launch_gemm_bf16(two, 1, e2, st, "bilinear dT = G Y | dY = G^T T");
+    if (rc) return rc;
+  }
   // dW[a, c] = sum_i X[i, a] dT[i, c]: A = X^T [dx][br], B = dT^T [dy][br], split over i into slabs
   // dX[i, a] = sum_c dT[i, c] W[a, c]: A = dT [br][dy], B = W [dx][dy]
   // Both only wait for dT: one launch (few tiles each; on their own they leave most CUs idle).

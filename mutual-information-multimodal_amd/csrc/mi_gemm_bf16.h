@@ -1186,6 +1186,8 @@ struct CvtJob {
   int64_t R, C;
   bf16_t* out_rm;
   bf16_t* out_t;
+  int n_slab;           // > 1: in holds n_slab partial sums [n_slab][R][C], added in slab order before the conversion
+  int64_t slab_stride;  // elements between slabs
 };
 struct CvtJobs {
   CvtJob j[3];
@@ -1203,7 +1205,10 @@ static __global__ __launch_bounds__(256) void cvt_transpose3_kernel(CvtJobs jobs
     const int rl = ty + 16 * q;
     const int64_t r = r0 + rl, c = c0 + 4 * tx;
     f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
-    if (r < J.R && c < J.C) v = *reinterpret_cast<const f32x4*>(J.in + r * J.C + c);
+    if (r < J.R && c < J.C) {
+      v = *reinterpret_cast<const f32x4*>(J.in + r * J.C + c);
+      for (int sl = 1; sl < J.n_slab; ++sl) v += *reinterpret_cast<const f32x4*>(J.in + sl * J.slab_stride + r * J.C + c);
+    }
 #pragma unroll
     for (int e = 0; e < 4; ++e) tile[rl][4 * tx + e] = v[e];
     if (J.out_rm && r < J.R && c < J.C) {
@@ -1234,7 +1239,9 @@ static __global__ __launch_bounds__(256) void cvt_transpose3_generic_kernel(CvtJ
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const int64_t r = r0 + ty + 8 * q, c = c0 + tx;
-    const float v = (r < J.R && c < J.C) ? J.in[r * J.C + c] : 0.0f;
+    float v = (r < J.R && c < J.C) ? J.in[r * J.C + c] : 0.0f;
+    if (r < J.R && c < J.C)
+      for (int sl = 1; sl < J.n_slab; ++sl) v += J.in[sl * J.slab_stride + r * J.C + c];
     tile[ty + 8 * q][tx] = v;
     if (J.out_rm && r < J.R && c < J.C) J.out_rm[r * J.C + c] = (bf16_t)v;
   }
@@ -1254,7 +1261,7 @@ static inline int launch_cvt_transpose3(const CvtJobs& jobs, hipStream_t st, con
     if (J.R > rmax) rmax = J.R;
     if (J.C > cmax) cmax = J.C;
     vec = vec && J.R % 4 == 0 && J.C % 4 == 0 && (uintptr_t)J.in % 16 == 0 && (uintptr_t)J.out_rm % 8 == 0 &&
-          (uintptr_t)J.out_t % 8 == 0;
+          (uintptr_t)J.out_t % 8 == 0 && J.slab_stride % 4 == 0;
   }
   {
     ProfScope prof_(what, st);
