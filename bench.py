@@ -43,11 +43,10 @@ def parse_args():
     p.add_argument("--estimator", default="infonce", choices=["dv", "infonce"])
     p.add_argument("--precision", default="bf16", choices=["bf16", "f32"])
     p.add_argument("--graph", default="auto", choices=["auto", "on", "off"],
-                   help="replay the step from hipGraphs.  auto: the bilinear step -- eagerly it is bound by the host's "
-                        "launch rate, not by the GPU: on one GPU the whole step is one graph; sharded over GPUs the two "
-                        "compute sections are graphs and the RCCL collectives stay eager between them.  The concat-MLP "
-                        "step (52 ms of kernels) stays eager: capturing it crashes inside capture_end on ROCm 7.2, "
-                        "which cannot be caught from Python")
+                   help="replay the step from hipGraphs (auto = on).  On one GPU the whole step is one graph; sharded "
+                        "over GPUs the two compute sections are graphs and the RCCL collectives stay eager between "
+                        "them.  Eagerly the bilinear step is bound by the host's launch rate, not by the GPU; for the "
+                        "concat-MLP step (51 ms of kernels) it makes no measurable difference")
     p.add_argument("--no-secondary", action="store_true")
     p.add_argument("--secondary-steps", type=int, default=5)
     p.add_argument("--no-cpu-baseline", action="store_true")
@@ -125,7 +124,9 @@ class Stepper:
         d = args.dim
         self.x, self.y, self.sid, self.full = make_inputs(args.batch, d, d, 3, rank, world, device)
         self.critic = make_critic(kind, d, d, 3, device)
-        self.params = critic_params(kind, self.critic)
+        # built per use: a cached w3.reshape(-1) keeps an autograd view (and w3's AccumulateGrad node, bound to the
+        # stream of this constructor) alive, which breaks the capture of a later backward
+        self.params_fn = lambda: critic_params(kind, self.critic)
         self.x.requires_grad_(True)
         self.y.requires_grad_(True)
         self.args = args
@@ -136,7 +137,7 @@ class Stepper:
             self._loss = lambda: mi_critics.fused_mi_bound(self.x, self.y, self.sid, self.critic, args.estimator,
                                                            precision=args.precision)
         else:
-            self._loss = lambda: global_batch_mi_bound(self.x, self.y, self.sid, self.params, args.estimator,
+            self._loss = lambda: global_batch_mi_bound(self.x, self.y, self.sid, self.params_fn(), args.estimator,
                                                        args.precision, critic=kind, group=group)
         self.loss = None
 
@@ -175,7 +176,8 @@ class Stepper:
     def try_staged(self, group):
         """Sharded step with its two compute sections replayed from hipGraphs and the collectives eager between them."""
         from mutual_info_img_txt.distributed import GlobalBatchGraphStep
-        self.staged = GlobalBatchGraphStep(self.x.detach(), self.y.detach(), self.sid, self.params, self.args.estimator,
+        self.staged = GlobalBatchGraphStep(self.x.detach(), self.y.detach(), self.sid,
+                                           [p.detach() for p in self.params_fn()], self.args.estimator,
                                            self.args.precision, critic=self.kind, group=group)
 
     def step(self):
@@ -330,7 +332,7 @@ def main():
     def run(kind, steps, warmup):
         st = Stepper(kind, args, rank, world, device, group)
         graph_used = False
-        want_graph = args.graph == "on" or (args.graph == "auto" and kind == "bilinear")
+        want_graph = args.graph in ("on", "auto")
         if want_graph:
             try:
                 if st.dist_mode:

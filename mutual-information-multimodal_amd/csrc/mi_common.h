@@ -158,6 +158,19 @@ __device__ __forceinline__ int pair_kind(int64_t gi, int64_t gj, int64_t sid_i, 
   return sid_i != sid_j ? 2 : 0;
 }
 
+// Raise a kernel's dynamic-LDS limit, once per size: hipFuncSetAttribute is host-side state, and calling it on every
+// launch also put such calls inside stream captures (the concat-MLP step could not be captured into a hipGraph).
+#define MI_SET_DYN_SMEM(fn, bytes, what)                                                                       \
+  do {                                                                                                         \
+    static size_t mi_cur_smem_ = 0;                                                                            \
+    if ((size_t)(bytes) > mi_cur_smem_) {                                                                      \
+      hipError_t mi_e_ = hipFuncSetAttribute((const void*)(fn), hipFuncAttributeMaxDynamicSharedMemorySize,    \
+                                             (int)(bytes));                                                    \
+      if (mi_e_ != hipSuccess) return hip_fail(mi_e_, what);                                                   \
+      mi_cur_smem_ = (size_t)(bytes);                                                                          \
+    }                                                                                                          \
+  } while (0)
+
 // XCD affinity for 1-D grids (speed only, never correctness: guide T1 / section 6 G16).  Workgroups are dealt
 // round-robin over the 8 XCDs in dispatch order, each XCD has a private L2: workgroup L runs on XCD L % 8 and is the
 // (L / 8)-th workgroup of that XCD.  Work items that share operand panels get the same `outer` index and run back to

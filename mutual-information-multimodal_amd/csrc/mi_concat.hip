@@ -130,16 +130,12 @@ static int launch_concat_fwd(const float* u, const float* v, const OpT* w2, cons
     static const bool regstage = getenv("MI_CONCAT_FWD_REGSTAGE") != nullptr;
     if (!regstage) {
       if (nwn == 2) {
-        hipError_t e = hipFuncSetAttribute((const void*)concat_fwd_dma_kernel<2>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, FwdDmaSmem<2>::TOTAL);
-        if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(concat_fwd_dma_kernel)");
+        MI_SET_DYN_SMEM((concat_fwd_dma_kernel<2>), FwdDmaSmem<2>::TOTAL, "hipFuncSetAttribute(concat_fwd_dma_kernel)");
         ProfScope prof_("concat_fwd_kernel", st);
         hipLaunchKernelGGL((concat_fwd_dma_kernel<2>), grid1d, dim3(512), FwdDmaSmem<2>::TOTAL, st, u, v, w2, b2, w3, b3,
                            br, b, h1, h2, scores, bitsP, bitsN, xcd_natural());
       } else {
-        hipError_t e = hipFuncSetAttribute((const void*)concat_fwd_dma_kernel<1>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, FwdDmaSmem<1>::TOTAL);
-        if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(concat_fwd_dma_kernel)");
+        MI_SET_DYN_SMEM((concat_fwd_dma_kernel<1>), FwdDmaSmem<1>::TOTAL, "hipFuncSetAttribute(concat_fwd_dma_kernel)");
         ProfScope prof_("concat_fwd_kernel", st);
         hipLaunchKernelGGL((concat_fwd_dma_kernel<1>), grid1d, dim3(256), FwdDmaSmem<1>::TOTAL, st, u, v, w2, b2, w3, b3,
                            br, b, h1, h2, scores, bitsP, bitsN, xcd_natural());
@@ -150,17 +146,13 @@ static int launch_concat_fwd(const float* u, const float* v, const OpT* w2, cons
   }
   if (nwn == 2) {
     const size_t smem = sizeof(FwdSmem<OpT, 2>);
-    hipError_t e = hipFuncSetAttribute((const void*)concat_fwd_kernel<OpT, 2>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(concat_fwd_kernel)");
+    MI_SET_DYN_SMEM((concat_fwd_kernel<OpT, 2>), smem, "hipFuncSetAttribute(concat_fwd_kernel)");
     ProfScope prof_("concat_fwd_kernel", st);
     hipLaunchKernelGGL((concat_fwd_kernel<OpT, 2>), grid, dim3(512), smem, st, u, v, w2, b2, w3, b3, br, b, h1, h2,
                        scores, bitsP, bitsN);
   } else {
     const size_t smem = sizeof(FwdSmem<OpT, 1>);
-    hipError_t e = hipFuncSetAttribute((const void*)concat_fwd_kernel<OpT, 1>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(concat_fwd_kernel)");
+    MI_SET_DYN_SMEM((concat_fwd_kernel<OpT, 1>), smem, "hipFuncSetAttribute(concat_fwd_kernel)");
     ProfScope prof_("concat_fwd_kernel", st);
     hipLaunchKernelGGL((concat_fwd_kernel<OpT, 1>), grid, dim3(256), smem, st, u, v, w2, b2, w3, b3, br, b, h1, h2,
                        scores, bitsP, bitsN);
@@ -190,9 +182,7 @@ static int concat_bwd_impl(const float* x, const float* y, const float* w1, cons
     size_t smem = (((size_t)DC::KC * ldw * sizeof(OpT)) + 15) & ~(size_t)15;
     smem += 256 * sizeof(bf16x8) + kDuvTI * kDuvTJ * sizeof(float) + kDuvTJ * DC::KC * sizeof(float) +
             4 * kDuvTJ * DC::KC * sizeof(float);
-    hipError_t e = hipFuncSetAttribute((const void*)concat_bwd_duv_kernel<OpT>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(concat_bwd_duv_kernel)");
+    MI_SET_DYN_SMEM((concat_bwd_duv_kernel<OpT>), smem, "hipFuncSetAttribute(concat_bwd_duv_kernel)");
     dim3 grid(xcd_grid((h1 + DC::KC - 1) / DC::KC, (int64_t)p.n_iblk * p.n_jsplit));
     {
       ProfScope prof_("concat_bwd_duv_kernel", st);
@@ -214,9 +204,7 @@ static int concat_bwd_impl(const float* x, const float* y, const float* w1, cons
   // ---- D = sum_p M g H1  ->  dW2, dW3, db2, db3 --------------------------------------------------------------------
   {
     const size_t smem = (256 * 36 + kDw2IB * 32) * sizeof(float) + 256 * sizeof(bf16x8);
-    hipError_t e = hipFuncSetAttribute((const void*)concat_bwd_dw2_kernel<OpT>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(concat_bwd_dw2_kernel)");
+    MI_SET_DYN_SMEM((concat_bwd_dw2_kernel<OpT>), smem, "hipFuncSetAttribute(concat_bwd_dw2_kernel)");
     dim3 grid(xcd_grid(((h1 + 255) / 256) * (h2 / 256), p.n_dsplit));
     {
       ProfScope prof_("concat_bwd_dw2_kernel", st);
@@ -226,9 +214,7 @@ static int concat_bwd_impl(const float* x, const float* y, const float* w1, cons
     }
     MI_LAUNCH_CHECK("concat_bwd_dw2_kernel");
     const size_t smem2 = (size_t)((b + 31) / 32) * 32 * sizeof(float);
-    e = hipFuncSetAttribute((const void*)concat_bwd_db2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)smem2);
-    if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(concat_bwd_db2_kernel)");
+    MI_SET_DYN_SMEM((concat_bwd_db2_kernel), smem2, "hipFuncSetAttribute(concat_bwd_db2_kernel)");
     {
       ProfScope prof_("concat_bwd_db2_kernel", st);
       hipLaunchKernelGGL(concat_bwd_db2_kernel, dim3((unsigned)p.n_msplit), dim3(512), smem2, st,
