@@ -96,6 +96,12 @@ def algorithmic_flops(kind, b, d_img, d_txt, h1=1024, h2=512):
 def kernel_flops(name, br, b, d_img, d_txt, h1=1024, h2=512):
     """Algorithmic flops of ONE launch of a named kernel (0 for HBM-bound helper kernels)."""
     if name.startswith("bilinear"):
+        if "fused S |" in name:  # scores + both B x B gradient contractions in one launch (no recompute credit)
+            return 6.0 * br * b * d_txt
+        if "fused S + LSE" in name:
+            return 2.0 * br * b * d_txt
+        if "from the fused sums" in name:
+            return 0.0
         if "dW" in name and "|" in name:  # two-problem launch: dW = X^T dT and dX = dT W^T
             return 4.0 * br * d_img * d_txt
         if "|" in name:  # two-problem launch: dT = G Y and dY = G^T T
@@ -223,6 +229,7 @@ def profile_kernels(stepper, steps):
 
 # profiling-hook kernel name -> substring of the rocprofv3 kernel name in profiles/*_pmc_traffic.json
 PMC_KERNEL_OF = {
+    "bilinear fused S | P Y | P^T T": "bilinear_flash_kernel",
     "bilinear dT = G Y | dY = G^T T": "gemm_bf16_pipe_kernel",
     "bilinear G": "gemm_bf16_big_kernel<mi::EpiGradScore2>",
     "bilinear score+LSE": "gemm_bf16_big_kernel<mi::EpiScoreLse2>",

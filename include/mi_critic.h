@@ -118,16 +118,19 @@ int mi_create_pairs_bwd(const float* grad_out, const int32_t* rowpos, int64_t b,
 /* X [b_rows, d_img] (the local row block), Y [b, d_txt] (all columns), W [d_img, d_txt], sid_rows [b_rows],
  * sid_cols [b]; row_offset = global index of local row 0 (diagonal of the global B x B matrix).  Single GPU:
  * b_rows = b, row_offset = 0.  scores_out (optional) [b_rows, b].  w == NULL selects the separable form
- * S = X Y^T on already-projected embeddings (d_img == d_txt; grad_w unused). */
+ * S = X Y^T on already-projected embeddings (d_img == d_txt; grad_w unused).
+ * need_grad != 0: the forward's fused B x B launch also accumulates the two gradient contractions (the loss has one
+ * global log-sum-exp, so they only need a scale once it is known); the matching backward then never recomputes scores. */
 size_t mi_bilinear_workspace_bytes(int64_t b_rows, int64_t b, int64_t d_img, int64_t d_txt, int precision);
 int mi_bilinear_fwd(const float* x, const float* y, const float* w, const int64_t* sid_rows,
                     const int64_t* sid_cols, int64_t b_rows, int64_t b, int64_t row_offset, int64_t d_img,
-                    int64_t d_txt, int estimator, int precision, float* loss_out, mi_stats* stats,
+                    int64_t d_txt, int estimator, int precision, int need_grad, float* loss_out, mi_stats* stats,
                     float* partials_out, float* scores_out, void* workspace, size_t workspace_bytes, void* stream);
 /* stats must hold the GLOBAL lse / n_pos (after the cross-rank merge when sharded). grad_out[0] = dL/dloss.
  * Outputs: grad_x [b_rows, d_img], grad_y [b, d_txt] (partial over this row block), grad_w [d_img, d_txt].
- * workspace_from_forward != 0: `workspace` is the buffer the matching mi_bilinear_fwd call wrote (same inputs); the
- * backward then reuses the bf16 operand copies and T found there instead of rebuilding them. */
+ * workspace_from_forward != 0: `workspace` is the buffer the matching mi_bilinear_fwd call wrote (same inputs,
+ * need_grad != 0); the backward then reuses the operand copies, T and the fused sums found there instead of
+ * rebuilding them. */
 int mi_bilinear_bwd(const float* x, const float* y, const float* w, const int64_t* sid_rows,
                     const int64_t* sid_cols, int64_t b_rows, int64_t b, int64_t row_offset, int64_t d_img,
                     int64_t d_txt, int precision, const mi_stats* stats, const float* grad_out, float* grad_x,

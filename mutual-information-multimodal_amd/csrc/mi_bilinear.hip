@@ -15,6 +15,7 @@
 // generic path (fp32 parity mode, odd shapes): mi_gemm.h kernels with strided operands, T recomputed in the backward.
 #include "mi_gemm.h"
 #include "mi_gemm_bf16.h"
+#include "mi_bilinear_flash.h"
 
 namespace mi {
 
@@ -34,6 +35,10 @@ struct BilinearPlan {
   float* dt_slab;
   int dt_splits;
   int64_t dt_kchunk;
+  // fused B x B stage (mi_bilinear_flash.h): partial sums and per-wave records of the two problems
+  FlashPlan fl;
+  float* fl_slab[2];
+  Partial* fl_rec[2];
   size_t bytes;
 };
 
@@ -55,6 +60,12 @@ static BilinearPlan plan_bilinear(Workspace& ws, int64_t br, int64_t b, int64_t 
   p.tb = ws.take<bf16_t>(br * dy);
   p.ttb = ws.take<bf16_t>(br * dy);
   p.t = ws.take<float>(br * dy);
+  p.fl = FlashPlan{};
+  if (precision == MI_PREC_BF16 && br % 8 == 0 && b % 8 == 0 && dx % 8 == 0) p.fl = flash_plan(br, b, dy);
+  for (int q = 0; q < 2; ++q) {
+    p.fl_rec[q] = p.fl.ok ? ws.take<Partial>(p.fl.n_rec[q]) : nullptr;
+    p.fl_slab[q] = p.fl.ok ? ws.take<float>(p.fl.slab_floats[q]) : nullptr;
+  }
   // backward
   p.dt = ws.take<float>(br * dy);
   if (precision == MI_PREC_BF16) p.g = ws.take<bf16_t>(br * b);
@@ -114,12 +125,40 @@ static int fast_prep_and_t(const float* x, const float* y, const float* w, int64
   return launch_gemm_bf16(one_problem(p.xb, dx, p.wtb, dx, br, dy, dx), 1, e, st, "bilinear T = X W");
 }
 
+static int bilinear_bwd_small(int64_t br, int64_t dx, int64_t dy, float* grad_x, float* grad_w, const BilinearPlan& p,
+                              hipStream_t st);
+
+// the fused B x B launch: scores, masked log-sum-exp partials and (grad) the unnormalised sums U, V of both gradient
+// contractions.  Problem 0 sweeps the text rows for every local image row, problem 1 the local image rows for every
+// text row.
+static int flash_stage(const int64_t* sid_rows, const int64_t* sid_cols, int64_t br, int64_t b, int64_t row_offset,
+                       int64_t dy, bool grad, const BilinearPlan& p, hipStream_t st) {
+  FlashArgs a{};
+  a.p[0] = FlashProblem{p.tb, p.yb, sid_rows, sid_cols, br, b, row_offset, p.fl.n_rb[0], p.fl.n_split[0],
+                        p.fl.tiles_per_split[0], p.fl_slab[0], p.fl_rec[0]};
+  a.p[1] = FlashProblem{p.yb, p.tb, sid_cols, sid_rows, b, br, -row_offset, p.fl.n_rb[1], p.fl.n_split[1],
+                        p.fl.tiles_per_split[1], p.fl_slab[1], p.fl_rec[1]};
+  a.n_problems = grad ? 2 : 1;
+  return launch_flash(a, dy, grad, st, grad ? "bilinear fused S | P Y | P^T T" : "bilinear fused S + LSE");
+}
+
 static int bilinear_fwd_fast(const float* x, const float* y, const float* w, const int64_t* sid_rows,
                              const int64_t* sid_cols, int64_t br, int64_t b, int64_t row_offset, int64_t dx, int64_t dy,
-                             int estimator, float* loss_out, mi_stats* stats, float* partials_out, float* scores_out,
-                             const BilinearPlan& p, hipStream_t st) {
+                             int estimator, int need_grad, float* loss_out, mi_stats* stats, float* partials_out,
+                             float* scores_out, const BilinearPlan& p, hipStream_t st) {
   int rc = fast_prep_and_t(x, y, w, br, b, dx, dy, p, st);
   if (rc) return rc;
+  if (p.fl.ok) {
+    rc = flash_stage(sid_rows, sid_cols, br, b, row_offset, dy, need_grad != 0, p, st);
+    if (rc) return rc;
+    if (scores_out) {  // per-pair scores are a diagnostic output: the stand-alone score GEMM writes them
+      rc = launch_gemm_bf16(one_problem(p.tb, dy, p.yb, dy, br, b, dy), 1,
+                            EpiScoreLse2{sid_rows, sid_cols, row_offset, scores_out, p.partials}, st,
+                            "bilinear score+LSE");
+      if (rc) return rc;
+    }
+    return launch_finalize(p.fl_rec[0], p.fl.n_rec[0], b, estimator, loss_out, stats, partials_out, st);
+  }
   rc = launch_gemm_bf16(one_problem(p.tb, dy, p.yb, dy, br, b, dy), 1,
                         EpiScoreLse2{sid_rows, sid_cols, row_offset, scores_out, p.partials}, st, "bilinear score+LSE");
   if (rc) return rc;
@@ -129,9 +168,24 @@ static int bilinear_fwd_fast(const float* x, const float* y, const float* w, con
 
 static int bilinear_bwd_fast(const int64_t* sid_rows, const int64_t* sid_cols, int64_t br, int64_t b, int64_t row_offset,
                              int64_t dx, int64_t dy, const mi_stats* stats, const float* grad_out, float* grad_x,
-                             float* grad_y, float* grad_w, const BilinearPlan& p, hipStream_t st) {
+                             float* grad_y, float* grad_w, const BilinearPlan& p, bool flash_sums, hipStream_t st) {
+  int rc = MI_OK;
+  if (flash_sums) {
+    // the forward's fused launch left U, V as slabs: scale by exp(m_ref - lse), subtract the diagonal term, add the
+    // slabs in a fixed order -> dT (bf16, both orientations, operands of dW | dX) and grad_y
+    FlashReduceArgs ra{};
+    ra.j[0] = FlashReduceJob{p.fl_slab[0], p.fl_rec[0], p.fl.n_split[0], p.fl.n_rb[0], br, p.yb, b, row_offset,
+                             nullptr, p.dtb, p.dttb};
+    ra.j[1] = FlashReduceJob{p.fl_slab[1], p.fl_rec[1], p.fl.n_split[1], p.fl.n_rb[1], b, p.tb, br, -row_offset,
+                             grad_y, nullptr, nullptr};
+    ra.stats = stats;
+    ra.grad_out = grad_out;
+    rc = launch_flash_reduce(ra, 2, dy, st, "bilinear dT, dY from the fused sums");
+    if (rc) return rc;
+    return bilinear_bwd_small(br, dx, dy, grad_x, grad_w, p, st);
+  }
   // G and G^T (bf16) from recomputed score tiles
-  int rc = launch_gemm_bf16(one_problem(p.tb, dy, p.yb, dy, br, b, dy), 1,
+  rc = launch_gemm_bf16(one_problem(p.tb, dy, p.yb, dy, br, b, dy), 1,
                             EpiGradScore2{sid_rows, sid_cols, row_offset, stats, grad_out, p.gb, p.gtb}, st,
                             "bilinear G");
   if (rc) return rc;
@@ -169,9 +223,15 @@ static int bilinear_bwd_fast(const int64_t* sid_rows, const int64_t* sid_cols, i
     rc = launch_gemm_bf16(two, 1, e2, st, "bilinear dT = G Y | dY = G^T T");
     if (rc) return rc;
   }
-  // dW[a, c] = sum_i X[i, a] dT[i, c]: A = X^T [dx][br], B = dT^T [dy][br], split over i into slabs
-  // dX[i, a] = sum_c dT[i, c] W[a, c]: A = dT [br][dy], B = W [dx][dy]
-  // Both only wait for dT: one launch (few tiles each; on their own they leave most CUs idle).
+  return bilinear_bwd_small(br, dx, dy, grad_x, grad_w, p, st);
+}
+
+// dW[a, c] = sum_i X[i, a] dT[i, c]: A = X^T [dx][br], B = dT^T [dy][br], split over i into slabs
+// dX[i, a] = sum_c dT[i, c] W[a, c]: A = dT [br][dy], B = W [dx][dy]
+// Both only wait for dT: one launch (few tiles each; on their own they leave most CUs idle).
+static int bilinear_bwd_small(int64_t br, int64_t dx, int64_t dy, float* grad_x, float* grad_w, const BilinearPlan& p,
+                              hipStream_t st) {
+  int rc = MI_OK;
   GemmBf16Args dwx{};
   dwx.p[0] = GemmBf16Problem{p.xtb, br, p.dttb, br, dx, dy, br};
   dwx.p[1] = GemmBf16Problem{p.dtb, dy, p.wb, dy, br, dx, dy};
@@ -273,8 +333,8 @@ size_t mi_bilinear_workspace_bytes(int64_t b_rows, int64_t b, int64_t d_img, int
 
 int mi_bilinear_fwd(const float* x, const float* y, const float* w, const int64_t* sid_rows, const int64_t* sid_cols,
                     int64_t b_rows, int64_t b, int64_t row_offset, int64_t d_img, int64_t d_txt, int estimator,
-                    int precision, float* loss_out, mi_stats* stats, float* partials_out, float* scores_out,
-                    void* workspace, size_t workspace_bytes, void* stream) {
+                    int precision, int need_grad, float* loss_out, mi_stats* stats, float* partials_out,
+                    float* scores_out, void* workspace, size_t workspace_bytes, void* stream) {
   MI_CHECK_ARG(x && y && sid_rows && sid_cols && stats && workspace, "mi_bilinear_fwd: null pointer");
   MI_CHECK_ARG(w || d_img == d_txt, "mi_bilinear_fwd: w == NULL (separable form) needs d_img == d_txt");
   int rc = check_common("mi_bilinear_fwd", b_rows, b, row_offset, d_img, d_txt, precision);
@@ -288,8 +348,8 @@ int mi_bilinear_fwd(const float* x, const float* y, const float* w, const int64_
   }
   hipStream_t st = (hipStream_t)stream;
   if (fast_ok(b_rows, b, d_img, d_txt, precision, w != nullptr))
-    return bilinear_fwd_fast(x, y, w, sid_rows, sid_cols, b_rows, b, row_offset, d_img, d_txt, estimator, loss_out,
-                             stats, partials_out, scores_out, p, st);
+    return bilinear_fwd_fast(x, y, w, sid_rows, sid_cols, b_rows, b, row_offset, d_img, d_txt, estimator, need_grad,
+                             loss_out, stats, partials_out, scores_out, p, st);
   if (precision == MI_PREC_BF16)
     return bilinear_fwd_impl<bf16_t>(x, y, w, sid_rows, sid_cols, b_rows, b, row_offset, d_img, d_txt, estimator,
                                      loss_out, stats, partials_out, scores_out, p, st);
@@ -315,12 +375,16 @@ int mi_bilinear_bwd(const float* x, const float* y, const float* w, const int64_
   }
   hipStream_t st = (hipStream_t)stream;
   if (fast_ok(b_rows, b, d_img, d_txt, precision, w != nullptr)) {
-    if (!workspace_from_forward) {  // rebuild the bf16 operand copies and T
+    if (!workspace_from_forward) {  // rebuild the bf16 operand copies, T and the fused sums
       rc = fast_prep_and_t(x, y, w, b_rows, b, d_img, d_txt, p, st);
       if (rc) return rc;
+      if (p.fl.ok) {
+        rc = flash_stage(sid_rows, sid_cols, b_rows, b, row_offset, d_txt, true, p, st);
+        if (rc) return rc;
+      }
     }
     return bilinear_bwd_fast(sid_rows, sid_cols, b_rows, b, row_offset, d_img, d_txt, stats, grad_out, grad_x, grad_y,
-                             grad_w, p, st);
+                             grad_w, p, p.fl.ok, st);
   }
   if (precision == MI_PREC_BF16)
     return bilinear_bwd_impl<bf16_t, bf16_t>(x, y, w, sid_rows, sid_cols, b_rows, b, row_offset, d_img, d_txt, stats,

@@ -1,0 +1,625 @@
+// Fused B x B stage of the bilinear critic (flash-attention shaped): scores, masked log-sum-exp AND the two B x B
+// gradient contractions in ONE launch, without ever writing S, G or G^T to HBM.
+//
+//   reference call site: mutual_info_img_txt/main_utils.py:220-226 (pairs -> critic -> bound -> backward); bound and
+//   masking semantics: mi_critics.py:3-23, main_utils.py:99-108.  The bilinear scorer itself is an extension.
+//
+// The loss has ONE global log-sum-exp (not one per row), so  dL/dS = go * (mask * exp(S - lse) - I / B)  factors as
+//   dT = go * (exp(m - lse) * U - Yb / B),   U = sum_j mask_ij exp(S_ij - m) Y_j      (m: any reference point)
+//   dY = go * (exp(m - lse) * V - Tb / B),   V = sum_i mask_ij exp(S_ij - m) T_i
+// and U, V can be accumulated in the same pass that produces the log-sum-exp: no recompute pass after the forward, no
+// materialised gradient matrix (the round-1 design wrote G and G^T, 2 x 33 MB, and read them back).
+//
+// Two "problems" share the kernel (one output-stationary sweep each; S tiles are recomputed per problem, which is
+// cheaper than a cross-workgroup reduction of a [B, d] fp32 output per tile):
+//   problem 0: stationary rows = T (local row block), streamed rows = Y (all columns)  -> U, LSE partials, positives
+//   problem 1: stationary rows = Y (all columns),     streamed rows = T (local rows)   -> V
+// A workgroup = 4 waves (one per SIMD, up to 512 registers each) owns 128 stationary rows, 32 per wave.  Per wave:
+//   * the 32 stationary rows live in registers as MFMA B fragments for the whole sweep (D / 16 fragments);
+//   * per streamed tile of 32 rows (LDS, filled by LDS-DMA, 4 stages): X = K Q^T (32 x 32 fp32, streamed row in the
+//     registers, stationary row on the lane) by D / 16 chained v_mfma_f32_32x32x16_bf16;
+//   * P = mask * exp(X - m_ref) in registers with a wave-uniform reference m_ref (raised, with a rescale of the
+//     accumulators, only when a tile maximum exceeds it by kFlThr); packed to bf16, the accumulator layout of X IS the A
+//     operand of the next product (guide: "an accumulator tile as the next MFMA's operand"), no LDS round trip;
+//   * O[32 x D] += P^T-as-A x V-tile, the tile read a second time from the SAME LDS image with ds_read_b64_tr_b16
+//     (image (b) of guide T10: chunk ^ (((row & 3) << 2) | ((row >> 2) & 3)) serves row reads and transposed reads
+//     conflict-free).
+// The streamed range is split over `n_split` workgroups per row block so that ~256 workgroups fill the chip; every
+// (problem, split) pair is pinned to one XCD (L % n_combo), whose 4 MB L2 then holds the streamed rows all its
+// workgroups sweep.  Partial O tiles go to fp32 slabs in accumulator order (16-byte stores, 1 KB per wave store) with
+// the wave's (m_ref, sum, positives, count) record; `flash_reduce_kernel` adds the slabs in a fixed order with the global
+// lse -- bit-reproducible, no float atomics.
+#pragma once
+#include <type_traits>
+
+#include "mi_common.h"
+
+namespace mi {
+
+constexpr int kFlRows = 128;     // stationary rows per workgroup
+constexpr int kFlBN = 32;        // streamed rows per tile
+constexpr int kFlStages = 4;     // LDS stages (three tiles in flight)
+constexpr float kFlThr = 24.0f;  // raise the reference point when a tile maximum exceeds it by this much
+constexpr int kFlMaxTilesPerSplit = 64;  // streamed study ids of a split sit in LDS: 64 tiles x 32 x 8 bytes = 16 KB
+
+struct FlashProblem {
+  const bf16_t* q;        // stationary operand [m][D]
+  const bf16_t* kv;       // streamed operand   [n][D]
+  const int64_t* sid_q;   // [m]
+  const int64_t* sid_kv;  // [n]
+  int64_t m, n;
+  int64_t diag;           // streamed index of the positive of stationary row i:  j == i + diag
+  int n_rb;               // row blocks of 128 stationary rows
+  int n_split;            // workgroups per row block
+  int tiles_per_split;
+  float* slab;            // [n_split][n_rb][4 waves][32 * D] partial sums in accumulator order
+  Partial* rec;           // [n_split][n_rb][4]
+};
+struct FlashArgs {
+  FlashProblem p[2];
+  int n_problems;
+  int n_combo;  // (problem, split) pairs, padded to a multiple of 8
+};
+
+template <int D>
+struct FlashCfg {
+  static constexpr int NK = D / 16;                    // 16-deep MFMA steps over the embedding width
+  static constexpr int NT = D / 32;                    // 32-wide output column tiles
+  static constexpr int RB = D * 2;                     // bytes per LDS row
+  static constexpr int CPR = RB / 16;                  // 16-byte chunks per row
+  static constexpr int RPP = 1024 / RB;                // rows per LDS-DMA piece
+  static constexpr int STAGE = kFlBN * RB;             // bytes per stage
+  static constexpr int PIECES = STAGE / 1024 / 4;      // LDS-DMA pieces per wave and tile
+  static constexpr int SID_OFF = kFlStages * STAGE;    // streamed study ids
+  static constexpr size_t SMEM = (size_t)SID_OFF + (size_t)kFlMaxTilesPerSplit * kFlBN * 8;
+  static constexpr int QA = NK / 2;                    // stationary fragments [0, QA) in accumulator registers
+  static constexpr int OA = NT >= 16 ? 12 : (NT >= 8 ? 4 : 0);  // output tiles [0, OA) in accumulator registers
+  static_assert(D == 128 || D == 256 || D == 512, "unsupported embedding width");
+};
+
+// swizzle of image (b), guide T10: XOR on the low four bits of the 16-byte chunk index
+__device__ __forceinline__ int fl_swz(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
+
+// wave-wide maximum as a wave-uniform value (DPP butterfly inside rows of 16, row broadcasts, lane 63)
+__device__ __forceinline__ float wave_max_uniform(float v) {
+  int x;
+#define MI_DPP_MAX(ctrl, rmask)                                                        \
+  x = __builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), ctrl, rmask, 0xF, false); \
+  v = fmaxf(v, __int_as_float(x));
+  MI_DPP_MAX(0xB1, 0xF)   // quad_perm [1,0,3,2]
+  MI_DPP_MAX(0x4E, 0xF)   // quad_perm [2,3,0,1]
+  MI_DPP_MAX(0x141, 0xF)  // row_half_mirror
+  MI_DPP_MAX(0x140, 0xF)  // row_mirror: every lane of a row holds the row maximum
+  MI_DPP_MAX(0x142, 0xA)  // row_bcast:15 into rows 1 and 3
+  MI_DPP_MAX(0x143, 0xC)  // row_bcast:31 into rows 2 and 3
+#undef MI_DPP_MAX
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
+template <int N>
+__device__ __forceinline__ void fl_wait_vmcnt_barrier() {
+  asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
+}
+
+// compile-time loop: f(std::integral_constant<int, I>) for I in [B, E)
+template <int B, int E, class F>
+__device__ __forceinline__ void fl_static_for(F&& f) {
+  if constexpr (B < E) {
+    f(std::integral_constant<int, B>{});
+    fl_static_for<B + 1, E>(f);
+  }
+}
+
+// MFMA wrappers with explicit register classes.  The 512 registers of a one-wave-per-SIMD kernel are 256 architectural
+// VGPRs plus 256 accumulator registers; hipcc (ROCm 7.2) keeps every MFMA A / B operand in the first file and, with the
+// 256 output accumulators in the second, spilled all 128 registers of stationary rows to scratch (215 spills, reloaded
+// every tile).  The hardware takes A, B and C / D from either file, so the split is made by hand: output tiles
+// [0, OA) and stationary fragments [0, QA) live in accumulator registers, the rest in VGPRs.
+// Hazards the compiler cannot see inside an asm statement are covered by hand (guide section 5.7 item 2):
+//   * a VALU-written operand needs two wait states before the MFMA reads it: FIRST = true puts an s_nop 1 in front;
+//   * an MFMA result needs the matrix pipe's passes before any non-MFMA reader: fl_mfma_drain() after a chain.
+template <bool B_IN_ACC, bool FIRST>
+__device__ __forceinline__ void fl_mfma_s(f32x16& acc, const bf16x8& a, const bf16x8& b) {
+  if constexpr (FIRST) {
+    if constexpr (B_IN_ACC) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=v"(acc) : "v"(a), "a"(b));
+    else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=v"(acc) : "v"(a), "v"(b));
+  } else {
+    if constexpr (B_IN_ACC) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "a"(b));
+    else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+  }
+}
+template <bool ACC_IN_ACC, bool FIRST>
+__device__ __forceinline__ void fl_mfma_o(f32x16& acc, const bf16x8& a, const bf16x8& b) {
+  if constexpr (FIRST) {
+    if constexpr (ACC_IN_ACC) asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+    else asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+  } else {
+    if constexpr (ACC_IN_ACC) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+    else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+  }
+}
+// Four transposed B fragments (two ds_read_b64_tr_b16 each) into FIXED registers, from asm: hipcc treats the tr-read
+// builtin as aliasing the LDS-DMA in flight and put an s_waitcnt vmcnt(0) in front of the first one of every tile, which
+// drained the three-tile prefetch.  An asm load's destination is only valid after the reader's own lgkmcnt wait (guide
+// 5.7 item 1), and one 4-register fragment is filled by two loads, so the registers are named literally: slot 0 =
+// v[224:239], slot 1 = v[240:255]; the fragments go straight into fl_mfma_o4, whose asm starts with the counted wait.
+template <int SLOT, int OFF_LO, int OFF_HI>
+__device__ __forceinline__ void fl_read_v4(bf16x8 (&f)[4], const int (&tb)[8]) {
+  static_assert(OFF_HI + 256 < 65536, "ds offset field");
+  if constexpr (SLOT == 0)
+    asm volatile("ds_read_b64_tr_b16 v[224:225], %4 offset:%c12\n\tds_read_b64_tr_b16 v[226:227], %5 offset:%c13\n\t"
+                 "ds_read_b64_tr_b16 v[228:229], %6 offset:%c12\n\tds_read_b64_tr_b16 v[230:231], %7 offset:%c13\n\t"
+                 "ds_read_b64_tr_b16 v[232:233], %8 offset:%c12\n\tds_read_b64_tr_b16 v[234:235], %9 offset:%c13\n\t"
+                 "ds_read_b64_tr_b16 v[236:237], %10 offset:%c12\n\tds_read_b64_tr_b16 v[238:239], %11 offset:%c13"
+                 : "={v[224:227]}"(f[0]), "={v[228:231]}"(f[1]), "={v[232:235]}"(f[2]), "={v[236:239]}"(f[3])
+                 : "v"(tb[0]), "v"(tb[1]), "v"(tb[2]), "v"(tb[3]), "v"(tb[4]), "v"(tb[5]), "v"(tb[6]), "v"(tb[7]),
+                   "i"(OFF_LO), "i"(OFF_HI));
+  else
+    asm volatile("ds_read_b64_tr_b16 v[240:241], %4 offset:%c12\n\tds_read_b64_tr_b16 v[242:243], %5 offset:%c13\n\t"
+                 "ds_read_b64_tr_b16 v[244:245], %6 offset:%c12\n\tds_read_b64_tr_b16 v[246:247], %7 offset:%c13\n\t"
+                 "ds_read_b64_tr_b16 v[248:249], %8 offset:%c12\n\tds_read_b64_tr_b16 v[250:251], %9 offset:%c13\n\t"
+                 "ds_read_b64_tr_b16 v[252:253], %10 offset:%c12\n\tds_read_b64_tr_b16 v[254:255], %11 offset:%c13"
+                 : "={v[240:243]}"(f[0]), "={v[244:247]}"(f[1]), "={v[248:251]}"(f[2]), "={v[252:255]}"(f[3])
+                 : "v"(tb[0]), "v"(tb[1]), "v"(tb[2]), "v"(tb[3]), "v"(tb[4]), "v"(tb[5]), "v"(tb[6]), "v"(tb[7]),
+                   "i"(OFF_LO), "i"(OFF_HI));
+}
+// wait until at most WAIT LDS reads are outstanding (the next chunk's eight), then four MFMAs o_e += P x V_e.
+// Compiler-issued LDS reads that slip in between only make the counted wait stronger (LDS returns in order).
+template <bool IN_ACC, bool FIRST, int WAIT>
+__device__ __forceinline__ void fl_mfma_o4(f32x16& o0, f32x16& o1, f32x16& o2, f32x16& o3, const bf16x8& p,
+                                           const bf16x8 (&f)[4]) {
+#define MI_FL_O4_BODY                                                                                       \
+  "s_waitcnt lgkmcnt(%c9)\n\ts_nop 1\n\t"                                                                  \
+  "v_mfma_f32_32x32x16_bf16 %0, %4, %5, %0\n\tv_mfma_f32_32x32x16_bf16 %1, %4, %6, %1\n\t"                 \
+  "v_mfma_f32_32x32x16_bf16 %2, %4, %7, %2\n\tv_mfma_f32_32x32x16_bf16 %3, %4, %8, %3"
+  (void)FIRST;
+  if constexpr (IN_ACC)
+    asm volatile(MI_FL_O4_BODY
+                 : "+a"(o0), "+a"(o1), "+a"(o2), "+a"(o3)
+                 : "v"(p), "v"(f[0]), "v"(f[1]), "v"(f[2]), "v"(f[3]), "i"(WAIT));
+  else
+    asm volatile(MI_FL_O4_BODY
+                 : "+v"(o0), "+v"(o1), "+v"(o2), "+v"(o3)
+                 : "v"(p), "v"(f[0]), "v"(f[1]), "v"(f[2]), "v"(f[3]), "i"(WAIT));
+#undef MI_FL_O4_BODY
+}
+
+// 20 wait states: covers the 8-pass and the 16-pass rule for "matrix result -> any other reader"
+__device__ __forceinline__ void fl_mfma_drain(f32x16& acc) { asm volatile("s_nop 15\n\ts_nop 3" : "+v"(acc)); }
+__device__ __forceinline__ void fl_mfma_drain_all() { asm volatile("s_nop 15\n\ts_nop 3" ::: "memory"); }
+// tile *= f (the rare rescale of the reference point).  For tiles in accumulator registers one asm statement per
+// register with ONE temporary: written as plain C++ the compiler reads all 192 accumulators into VGPRs first, and the
+// register pressure of that block alone made it spill the stationary rows in the main loop.
+template <bool IN_ACC>
+__device__ __forceinline__ void fl_scale_tile(f32x16& t, float f) {
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    if constexpr (IN_ACC) {
+      float e = t[r], tmp;
+      asm volatile("v_accvgpr_read_b32 %1, %0\n\tv_mul_f32 %1, %1, %2\n\tv_accvgpr_write_b32 %0, %1"
+                   : "+a"(e), "=&v"(tmp)
+                   : "v"(f));
+      t[r] = e;
+    } else {
+      t[r] *= f;
+    }
+  }
+}
+template <bool IN_ACC>
+__device__ __forceinline__ void fl_pin(bf16x8& v) {
+  if constexpr (IN_ACC) asm volatile("" : "+a"(v));
+  else asm volatile("" : "+v"(v));
+}
+template <bool IN_ACC>
+__device__ __forceinline__ void fl_pin_o(f32x16& v) {
+  if constexpr (IN_ACC) asm volatile("" : "+a"(v));
+  else asm volatile("" : "+v"(v));
+}
+
+template <int D, bool GRAD>
+__global__ __launch_bounds__(256, 1) void bilinear_flash_kernel(FlashArgs args) {
+  using C = FlashCfg<D>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  // ---- which (problem, split, row block)
+  const int L = (int)blockIdx.x;
+  const int combo = L % args.n_combo, rb = L / args.n_combo;
+  int prob, split;
+  if (combo < args.p[0].n_split) {
+    prob = 0;
+    split = combo;
+  } else if (args.n_problems == 2 && combo < args.p[0].n_split + args.p[1].n_split) {
+    prob = 1;
+    split = combo - args.p[0].n_split;
+  } else {
+    return;
+  }
+  const FlashProblem& P = args.p[prob];
+  if (rb >= P.n_rb) return;
+  const int64_t n_tiles_all = P.n / kFlBN;
+  const int64_t tile0 = (int64_t)split * P.tiles_per_split;
+  int nt = (int)(n_tiles_all - tile0 < P.tiles_per_split ? n_tiles_all - tile0 : P.tiles_per_split);
+  if (nt < 0) nt = 0;
+
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int r32 = lane & 31, half = lane >> 5;
+  const int64_t m_wave = (int64_t)rb * kFlRows + wave * 32;  // first stationary row of this wave
+  const bool wave_active = m_wave < P.m;                      // P.m % 32 == 0: a wave is all in or all out
+  const int64_t gi = wave_active ? m_wave + r32 : r32;  // an idle wave re-reads rows 0..31; its outputs are dropped
+
+  // ---- LDS-DMA pieces of this wave: piece q = PIECES * wave + i covers tile rows [q * RPP, (q + 1) * RPP)
+  const char* kv_base = reinterpret_cast<const char*>(P.kv + tile0 * kFlBN * D);
+  int src_off[C::PIECES];
+#pragma unroll
+  for (int i = 0; i < C::PIECES; ++i) {
+    const int q = C::PIECES * wave + i;
+    const int row = q * C::RPP + lane / C::CPR;
+    const int cp = lane % C::CPR;
+    src_off[i] = row * C::RB + 16 * (cp ^ fl_swz(row));
+  }
+  auto issue_tile = [&](int t) {
+    const int stage = t & (kFlStages - 1);
+    const char* src = kv_base + (int64_t)t * C::STAGE;
+#pragma unroll
+    for (int i = 0; i < C::PIECES; ++i)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + src_off[i]),
+                                       (__attribute__((address_space(3))) void*)(smem + stage * C::STAGE +
+                                                                                (C::PIECES * wave + i) * 1024),
+                                       16, 0, 0);
+  };
+  if (nt > 0) issue_tile(0);
+  if (nt > 1) issue_tile(1);
+  if (nt > 2) issue_tile(2);
+
+  // ---- stationary rows as B fragments: lane (n = r32, half) holds Q[gi][16 kk + 8 half .. + 7]
+  bf16x8 qf[C::NK];
+  {
+    const bf16_t* qrow = P.q + gi * D + 8 * half;
+#pragma unroll
+    for (int kk = 0; kk < C::NK; ++kk) qf[kk] = *reinterpret_cast<const bf16x8*>(qrow + 16 * kk);
+  }
+  const int64_t sid_i = P.sid_q[gi];
+  // streamed study ids of this split -> LDS (plain loads: done before the pipeline's counted waits start)
+  {
+    int64_t* sl = reinterpret_cast<int64_t*>(smem + C::SID_OFF);
+    const int64_t* sg = P.sid_kv + tile0 * kFlBN;
+    for (int e = tid; e < nt * kFlBN; e += 256) sl[e] = sg[e];
+  }
+
+  constexpr int NO = GRAD ? C::NT : 1;
+  f32x16 o[NO];
+#pragma unroll
+  for (int c = 0; c < NO; ++c)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[c][r] = 0.0f;
+  float lsum = 0.0f, pos = 0.0f;
+  unsigned cnt = 0;                // wave-uniform
+  float mref = MI_NEG_INF;         // wave-uniform reference point of the exponentials
+  constexpr float kLog2e = 1.4426950408889634f;
+
+  // per-lane constants of the fragment addresses (derivations: DESIGN.md section 4)
+  const int fxh = half ^ fl_swz(r32);                       // row read: chunk (2 kk + half) ^ swz(row)
+  const int a0_lane = r32 * C::RB + 16 * fxh;
+  const int g16 = lane >> 4, q4 = (lane & 15) >> 2, p4 = lane & 3;
+  const int cl = 2 * (g16 & 1) + (p4 >> 1);
+  const int a1_lane = (4 * half + q4) * C::RB + 16 * ((cl ^ half) | (q4 << 2)) + 8 * (p4 & 1);
+  const int d0_wave = (int)(m_wave + P.diag - tile0 * kFlBN);  // streamed offset of the wave's first positive
+
+  // the Q loads, the id copy and the first tiles must have landed
+  __syncthreads();  // hipcc drains vmcnt to 0 here (plain loads and LDS-DMA alike)
+  // pin the register classes once: from here on only the asm MFMAs touch these values
+  fl_static_for<0, C::NK>([&](auto KK) { fl_pin<(decltype(KK)::value < C::QA)>(qf[decltype(KK)::value]); });
+  if constexpr (GRAD) fl_static_for<0, C::NT>([&](auto CT) { fl_pin_o<(decltype(CT)::value < C::OA)>(o[decltype(CT)::value]); });
+
+  for (int t = 0; t < nt; ++t) {
+    // ---- wait for tile t (own pieces), make every wave's pieces visible, refill the stage read one tile ago
+    if (t > 0) {
+      if (t + 2 < nt) fl_wait_vmcnt_barrier<2 * C::PIECES>();
+      else if (t + 1 < nt) fl_wait_vmcnt_barrier<C::PIECES>();
+      else fl_wait_vmcnt_barrier<0>();
+    }
+    if (t + 3 < nt) issue_tile(t + 3);
+    const int stage_off = (t & (kFlStages - 1)) * C::STAGE;
+
+    // ---- X = K Q^T: streamed rows in the registers, stationary rows on the lanes.  Fragment reads run one chunk of
+    // four 16-deep steps ahead of the MFMAs; the scheduling fences bound the fragments in flight.
+    f32x16 s;
+    {
+      int abase[8];
+#pragma unroll
+      for (int v = 0; v < 8; ++v) abase[v] = (stage_off + a0_lane) ^ (32 * v);
+      constexpr int CH = 4, NCH = C::NK / CH;
+      bf16x8 kf[2][CH];
+#pragma unroll
+      for (int e = 0; e < CH; ++e) kf[0][e] = *reinterpret_cast<const bf16x8*>(smem + abase[e & 7] + 256 * (e >> 3));
+      fl_static_for<0, NCH>([&](auto CI) {
+        constexpr int c = decltype(CI)::value;
+        if constexpr (c + 1 < NCH) {
+#pragma unroll
+          for (int e = 0; e < CH; ++e) {
+            const int kk = (c + 1) * CH + e;
+            kf[(c + 1) & 1][e] = *reinterpret_cast<const bf16x8*>(smem + abase[kk & 7] + 256 * (kk >> 3));
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        fl_static_for<0, CH>([&](auto EI) {
+          constexpr int e = decltype(EI)::value, kk = c * CH + e;
+          fl_mfma_s<(kk < C::QA), kk == 0>(s, kf[c & 1][e], qf[kk]);
+        });
+        __builtin_amdgcn_sched_barrier(0);
+      });
+      fl_mfma_drain(s);
+    }
+
+    // ---- mask, positives, reference point, exponentials
+    const int64_t* sl = reinterpret_cast<const int64_t*>(smem + C::SID_OFF) + t * kFlBN + 4 * half;
+    const int d0 = d0_wave - t * kFlBN;  // streamed row (inside this tile) of stationary row 0's positive
+    if (__builtin_amdgcn_readfirstlane((int)(d0 > -32 && d0 < 32))) {
+      const int want = r32 + d0 - 4 * half;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) pos += (want == (r & 3) + 8 * (r >> 2)) ? s[r] : 0.0f;
+    }
+    float tmax = MI_NEG_INF;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const bool neg = sl[(r & 3) + 8 * (r >> 2)] != sid_i;
+      cnt += (unsigned)__popcll(__ballot(neg));
+      s[r] = neg ? s[r] : MI_NEG_INF;
+      tmax = fmaxf(tmax, s[r]);
+    }
+    tmax = wave_max_uniform(tmax);
+    if (tmax > mref + kFlThr || (mref == MI_NEG_INF && tmax > MI_NEG_INF)) {
+      if (mref > MI_NEG_INF) {
+        const float f = __builtin_amdgcn_exp2f((mref - tmax) * kLog2e);
+        lsum *= f;
+        if constexpr (GRAD) {
+          fl_mfma_drain_all();
+          fl_static_for<0, C::NT>([&](auto CT) { fl_scale_tile<(decltype(CT)::value < C::OA)>(o[decltype(CT)::value], f); });
+        }
+      }
+      mref = tmax;
+    }
+    const float off = mref > MI_NEG_INF ? -mref * kLog2e : 0.0f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      s[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[r], kLog2e, off));  // masked entries: exp2(-inf) = 0
+      lsum += s[r];
+    }
+
+    if constexpr (GRAD) {
+      // ---- O += P (A operand straight from the accumulator layout) x V (transposed reads of the same tile)
+      bf16x8 pf[2];
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) pf[ks][e] = (bf16_t)s[8 * ks + e];
+      int tbase[8];  // index 2 * (ct & 3) + tt
+#pragma unroll
+      for (int v = 0; v < 8; ++v) tbase[v] = (stage_off + a1_lane) ^ (16 * ((4 * (v >> 1)) ^ (2 * (v & 1))));
+      // step u = ks * NT + ct in chunks of four (one chunk = one ks, four consecutive column tiles): the transposed
+      // reads of chunk c + 1 are issued, then the MFMAs of chunk c run behind a counted lgkmcnt.
+      constexpr int NCH = 2 * C::NT / 4, CPK = C::NT / 4;  // chunks; chunks per ks
+      bf16x8 vf[2][4];
+      fl_read_v4<0, 0, 8 * C::RB>(vf[0], tbase);
+      fl_static_for<0, NCH>([&](auto CI) {
+        constexpr int c = decltype(CI)::value, ks = c / CPK, ct0 = 4 * (c % CPK);
+        if constexpr (c + 1 < NCH) {
+          constexpr int c1 = c + 1, ks1 = c1 / CPK, hi1 = c1 % CPK;
+          fl_read_v4<(c1 & 1), 256 * hi1 + 16 * ks1 * C::RB, 256 * hi1 + (16 * ks1 + 8) * C::RB>(vf[c1 & 1], tbase);
+        }
+        fl_mfma_o4<(ct0 < C::OA), (c % CPK == 0), (c + 1 < NCH ? 8 : 0)>(o[ct0], o[ct0 + 1], o[ct0 + 2], o[ct0 + 3], pf[ks],
+                                                                       vf[c & 1]);
+      });
+    }
+  }
+
+  // ---- records and partial sums
+  lsum = wave_sum(lsum);
+  pos = wave_sum(pos);
+  if (lane == 0) {
+    Partial rec{mref, lsum, pos, cnt};
+    if (!wave_active) rec = Partial{MI_NEG_INF, 0.0f, 0.0f, 0u};
+    P.rec[((int64_t)split * P.n_rb + rb) * 4 + wave] = rec;
+  }
+  if constexpr (GRAD) {
+    fl_mfma_drain_all();
+    if (wave_active) {
+      float* dst = P.slab + (((int64_t)split * P.n_rb + rb) * 4 + wave) * (32 * D) + lane * 4;
+#pragma unroll
+      for (int c = 0; c < C::NT; ++c)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const f32x4 v = {o[c][4 * g], o[c][4 * g + 1], o[c][4 * g + 2], o[c][4 * g + 3]};
+          *reinterpret_cast<f32x4*>(dst + c * 1024 + g * 256) = v;
+        }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ slab reduce
+// out[i][c] = go * ( sum_s exp(m_ref[s][i / 32] - lse) * slab_s[i][c]  -  other[i + diag][c] / n_pos )
+// One workgroup per (32-row wave block, 128 columns).  Outputs: fp32 row-major (grad_y) and / or bf16 row-major and
+// transposed (dT for the dW | dX products).
+struct FlashReduceJob {
+  const float* slab;
+  const Partial* rec;
+  int n_split, n_rb;
+  int64_t m;              // rows
+  const bf16_t* other;    // [n_other][D]: the rows subtracted on the diagonal (Yb for dT, Tb for dY)
+  int64_t n_other, diag;
+  float* out_f32;         // [m][D] or null
+  bf16_t* out_bf;         // [m][D] or null
+  bf16_t* out_bf_t;       // [D][m] or null
+};
+struct FlashReduceArgs {
+  FlashReduceJob j[2];
+  const mi_stats* stats;
+  const float* grad_out;
+};
+
+template <int D>
+__global__ __launch_bounds__(256) void flash_reduce_kernel(FlashReduceArgs args) {
+  __shared__ float tile[32][129];
+  const FlashReduceJob& J = args.j[blockIdx.z];
+  const int64_t wb = blockIdx.y;  // 32-row block
+  const int cc = blockIdx.x;      // 128-column chunk
+  if (wb * 32 >= J.m) return;
+  const int rb = (int)(wb >> 2), w = (int)(wb & 3);
+  const float go = args.grad_out ? args.grad_out[0] : 1.0f;
+  const float lse = args.stats->lse;
+  const float gpos = go / (float)args.stats->n_pos;
+  const int tid = threadIdx.x;
+  f32x4 acc[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) acc[u] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+  for (int s = 0; s < J.n_split; ++s) {
+    const int64_t wv = ((int64_t)s * J.n_rb + rb) * 4 + w;
+    const float m = J.rec[wv].m;
+    if (!(m > MI_NEG_INF)) continue;  // nothing accumulated by that wave
+    const float c = go * __expf(m - lse);
+    const float* src = J.slab + wv * (32 * D) + (int64_t)cc * 4 * 1024;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(src + (u * 256 + tid) * 4);
+      acc[u] += v * c;
+    }
+  }
+  // element (u, tid): float4 index f = u * 256 + tid = ct_l * 256 + g * 64 + lane
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int f = u * 256 + tid;
+    const int ct_l = f >> 8, g = (f >> 6) & 3, lane = f & 63;
+    const int col = ct_l * 32 + (lane & 31), row0 = 8 * g + 4 * (lane >> 5);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) tile[row0 + e][col] = acc[u][e];
+  }
+  __syncthreads();
+  const int64_t i0 = wb * 32;
+  const int64_t c0 = (int64_t)cc * 128;
+  {
+    // row-major outputs: thread -> row tid >> 3, 16 columns
+    const int row = tid >> 3, cs = (tid & 7) * 16;
+    const int64_t i = i0 + row, jo = i + J.diag;
+    float v[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) v[e] = tile[row][cs + e];
+    if (jo >= 0 && jo < J.n_other) {
+      const bf16x8 a = *reinterpret_cast<const bf16x8*>(J.other + jo * D + c0 + cs);
+      const bf16x8 b = *reinterpret_cast<const bf16x8*>(J.other + jo * D + c0 + cs + 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        v[e] -= gpos * (float)a[e];
+        v[8 + e] -= gpos * (float)b[e];
+      }
+#pragma unroll
+      for (int e = 0; e < 16; ++e) tile[row][cs + e] = v[e];  // the transposed output reads the tile again
+    }
+    if (J.out_f32) {
+#pragma unroll
+      for (int e = 0; e < 16; e += 4)
+        *reinterpret_cast<f32x4*>(J.out_f32 + i * D + c0 + cs + e) = f32x4{v[e], v[e + 1], v[e + 2], v[e + 3]};
+    }
+    if (J.out_bf) {
+      bf16x8 a, b;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        a[e] = (bf16_t)v[e];
+        b[e] = (bf16_t)v[8 + e];
+      }
+      *reinterpret_cast<bf16x8*>(J.out_bf + i * D + c0 + cs) = a;
+      *reinterpret_cast<bf16x8*>(J.out_bf + i * D + c0 + cs + 8) = b;
+    }
+  }
+  if (J.out_bf_t) {
+    __syncthreads();
+    // transposed output [D][m]: thread -> column tid >> 1, 16 rows
+    const int col = tid >> 1, rs = (tid & 1) * 16;
+    bf16x8 a, b;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      a[e] = (bf16_t)tile[rs + e][col];
+      b[e] = (bf16_t)tile[rs + 8 + e][col];
+    }
+    bf16_t* dst = J.out_bf_t + (c0 + col) * J.m + i0 + rs;
+    *reinterpret_cast<bf16x8*>(dst) = a;
+    *reinterpret_cast<bf16x8*>(dst + 8) = b;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+struct FlashPlan {
+  bool ok;
+  int n_split[2], n_rb[2], tiles_per_split[2];
+  int64_t slab_floats[2], n_rec[2];
+};
+
+static inline bool flash_width_ok(int64_t d) { return d == 128 || d == 256 || d == 512; }
+
+// problem 0: stationary [br] x streamed [b]; problem 1: stationary [b] x streamed [br]
+static inline FlashPlan flash_plan(int64_t br, int64_t b, int64_t d) {
+  FlashPlan fp{};
+  static const bool off = getenv("MI_NO_FLASH") != nullptr;  // A/B switch: the round-1 G-materialising path
+  fp.ok = !off && flash_width_ok(d) && br % 32 == 0 && b % 32 == 0 && br >= 32;
+  if (!fp.ok) return fp;
+  const int64_t m[2] = {br, b}, n[2] = {b, br};
+  int64_t total_tiles = 0;
+  for (int q = 0; q < 2; ++q) {
+    fp.n_rb[q] = (int)((m[q] + kFlRows - 1) / kFlRows);
+    total_tiles += (int64_t)fp.n_rb[q] * (n[q] / kFlBN);
+  }
+  int64_t tau = (total_tiles + 255) / 256;  // streamed tiles per workgroup for ~256 workgroups
+  if (tau < 4) tau = 4;
+  if (tau > kFlMaxTilesPerSplit) tau = kFlMaxTilesPerSplit;
+  if (const char* e = getenv("MI_FLASH_TILES")) tau = atoi(e) > 0 ? atoi(e) : tau;  // A/B switch
+  for (int q = 0; q < 2; ++q) {
+    const int64_t tiles = n[q] / kFlBN;
+    int64_t tps = tau < tiles ? tau : tiles;
+    fp.n_split[q] = (int)((tiles + tps - 1) / tps);
+    fp.tiles_per_split[q] = (int)((tiles + fp.n_split[q] - 1) / fp.n_split[q]);  // balanced
+    fp.n_split[q] = (int)((tiles + fp.tiles_per_split[q] - 1) / fp.tiles_per_split[q]);
+    fp.n_rec[q] = (int64_t)fp.n_split[q] * fp.n_rb[q] * 4;
+    fp.slab_floats[q] = fp.n_rec[q] * 32 * d;
+  }
+  return fp;
+}
+
+template <int D, bool GRAD>
+static inline int launch_flash_t(const FlashArgs& a, unsigned grid, hipStream_t st, const char* what) {
+  MI_SET_DYN_SMEM((bilinear_flash_kernel<D, GRAD>), FlashCfg<D>::SMEM, "hipFuncSetAttribute(bilinear_flash_kernel)");
+  {
+    ProfScope prof_(what, st);
+    hipLaunchKernelGGL((bilinear_flash_kernel<D, GRAD>), dim3(grid), dim3(256), FlashCfg<D>::SMEM, st, a);
+  }
+  MI_LAUNCH_CHECK(what);
+  return MI_OK;
+}
+
+static inline int launch_flash(FlashArgs a, int64_t d, bool grad, hipStream_t st, const char* what) {
+  int combos = a.p[0].n_split + (a.n_problems == 2 ? a.p[1].n_split : 0);
+  a.n_combo = (combos + 7) / 8 * 8;
+  int max_rb = a.p[0].n_rb;
+  if (a.n_problems == 2 && a.p[1].n_rb > max_rb) max_rb = a.p[1].n_rb;
+  const unsigned grid = (unsigned)(a.n_combo * max_rb);
+  if (d == 512) return grad ? launch_flash_t<512, true>(a, grid, st, what) : launch_flash_t<512, false>(a, grid, st, what);
+  if (d == 256) return grad ? launch_flash_t<256, true>(a, grid, st, what) : launch_flash_t<256, false>(a, grid, st, what);
+  if (d == 128) return grad ? launch_flash_t<128, true>(a, grid, st, what) : launch_flash_t<128, false>(a, grid, st, what);
+  set_error("launch_flash: unsupported width %lld", (long long)d);
+  return MI_ESHAPE;
+}
+
+static inline int launch_flash_reduce(const FlashReduceArgs& a, int n_jobs, int64_t d, hipStream_t st, const char* what) {
+  int64_t mmax = a.j[0].m;
+  if (n_jobs == 2 && a.j[1].m > mmax) mmax = a.j[1].m;
+  dim3 grid((unsigned)(d / 128), (unsigned)(mmax / 32), (unsigned)n_jobs);
+  {
+    ProfScope prof_(what, st);
+    if (d == 512) hipLaunchKernelGGL(flash_reduce_kernel<512>, grid, dim3(256), 0, st, a);
+    else if (d == 256) hipLaunchKernelGGL(flash_reduce_kernel<256>, grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(flash_reduce_kernel<128>, grid, dim3(256), 0, st, a);
+  }
+  MI_LAUNCH_CHECK(what);
+  return MI_OK;
+}
+
+}  // namespace mi

@@ -43,7 +43,7 @@ SIGNATURES = {
     "mi_create_pairs": (c_int, [_P, _P, _P, _P, _I64, _I64, _I64, _P, _P]),
     "mi_create_pairs_bwd": (c_int, [_P, _P, _I64, _I64, _I64, _P, _P, _P]),
     "mi_bilinear_workspace_bytes": (_SZ, [_I64, _I64, _I64, _I64, _I]),
-    "mi_bilinear_fwd": (c_int, [_P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I, _I, _P, _P, _P, _P, _P, _SZ, _P]),
+    "mi_bilinear_fwd": (c_int, [_P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I, _I, _I, _P, _P, _P, _P, _P, _SZ, _P]),
     "mi_bilinear_bwd": (c_int, [_P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I, _P, _P, _P, _P, _P, _P, _SZ, _I, _P]),
     "mi_concat_mlp_workspace_bytes": (_SZ, [_I64, _I64, _I64, _I64, _I64, _I64, _I, _I]),
     "mi_concat_mlp_fwd": (c_int, [_P] * 10 + [_I64] * 7 + [_I, _I, _I] + [_P] * 5 + [_SZ, _P]),

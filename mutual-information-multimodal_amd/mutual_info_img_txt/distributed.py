@@ -42,7 +42,8 @@ class HipBilinearOps:
         record = torch.empty(_hip.RECORD_FLOATS, dtype=torch.float32, device=dev)
         _hip.check(lib.mi_bilinear_fwd(x.data_ptr(), y_all.data_ptr(), w.data_ptr(), sid_rows.data_ptr(),
                                        sid_all.data_ptr(), br, b, row_offset, dx, dy, estimator, precision,
-                                       loss.data_ptr(), stats.data_ptr(), record.data_ptr(), None, ws.data_ptr(),
+                                       int(bool(need_grad)), loss.data_ptr(), stats.data_ptr(), record.data_ptr(), None,
+                                       ws.data_ptr(),
                                        ws.numel(), _hip.stream_ptr()), "mi_bilinear_fwd")
         return record, (x, y_all, w, sid_rows, sid_all, row_offset, precision, ws)
 

@@ -174,8 +174,9 @@ class BilinearCriticFn(torch.autograd.Function):
         loss = torch.empty(1, dtype=torch.float32, device=dev)
         record = torch.empty(_hip.RECORD_FLOATS, dtype=torch.float32, device=dev)
         scores = torch.empty(b, b, dtype=torch.float32, device=dev) if want_scores else None
+        need_grad = 1 if any(ctx.needs_input_grad[:3]) else 0
         _hip.check(lib.mi_bilinear_fwd(x.data_ptr(), y.data_ptr(), _hip.ptr(w), sid.data_ptr(), sid.data_ptr(), b, b, 0,
-                                       dx, dy, estimator, precision, loss.data_ptr(), stats.data_ptr(),
+                                       dx, dy, estimator, precision, need_grad, loss.data_ptr(), stats.data_ptr(),
                                        record.data_ptr(), _hip.ptr(scores), ws.data_ptr(), ws.numel(),
                                        _hip.stream_ptr()), "mi_bilinear_fwd")
         ctx.save_for_backward(x, y, sid, stats, ws, *([] if w is None else [w]))
@@ -216,7 +217,7 @@ class ConcatMlpCriticFn(torch.autograd.Function):
         dy = y.shape[1]
         h1, h2 = params[0].shape[0], params[2].shape[0]
         dev = x.device
-        need_grad = 1 if any(t.requires_grad for t in (x, y, w1, b1, w2, b2, w3, b3)) else 0
+        need_grad = 1 if any(ctx.needs_input_grad[:8]) else 0
         ws = _hip.workspace(lib.mi_concat_mlp_workspace_bytes(b, b, dx, dy, h1, h2, precision, need_grad), dev)
         stats = _hip.new_stats(dev)
         loss = torch.empty(1, dtype=torch.float32, device=dev)

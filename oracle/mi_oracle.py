@@ -222,6 +222,30 @@ def bilinear_scores(x, y, w, round_fn=None) -> torch.Tensor:
     return t @ round_fn(y).t()
 
 
+def bilinear_step_rounded(x, y, w, study_id: Sequence, estimator: str, row_block: Optional[Tuple[int, int]] = None):
+    """Extension (no reference code).  fp64 forward + backward of S = (x W) y^T under the reference bound with the
+    rounding points of the 16-bit MFMA path (mi_bilinear_flash.h): x, y, w and T = x W are rounded to bf16; the
+    exponentials P = exp(S - lse) are rounded to bf16 before the two B x B gradient contractions; dT is rounded to
+    bf16 before dW = x^T dT and dX = dT w^T.  (The kernel exponentiates against a per-wave reference point instead of
+    lse; bf16 rounding is scale invariant up to the position of the binade boundaries, which the tolerance covers.)
+    ``row_block`` = (r0, r1): only the image rows [r0, r1) contribute (the sharded case): dY is then the partial sum of
+    that row block, dX / dW likewise, and the statistics are still those of the full matrix."""
+    xb, yb, wb = round_bf16(x.double()), round_bf16(y.double()), round_bf16(w.double())
+    tb = round_bf16(xb @ wb)
+    s = tb @ yb.t()
+    b = s.shape[0]
+    neg = negative_mask(study_id)
+    lse = torch.logsumexp(s[neg], dim=0)
+    loss = bound_from_matrix(s, study_id, estimator)
+    p = round_bf16(torch.where(neg, torch.exp(s - lse), torch.zeros_like(s)))
+    r0, r1 = (0, b) if row_block is None else row_block
+    rows = slice(r0, r1)
+    eye = torch.eye(b, dtype=s.dtype)[rows]
+    dt = round_bf16(p[rows] @ yb - (eye @ yb) / b)
+    dy = p[rows].t() @ tb[rows] - (eye.t() @ tb[rows]) / b
+    return {"scores": s, "loss": loss, "dx": dt @ wb.t(), "dy": dy, "dw": xb[rows].t() @ dt, "dt": dt}
+
+
 def separable_scores(x, y, wg, wh) -> torch.Tensor:
     """Extension (no reference code): S = (x Wg)(y Wh)^T."""
     return (x @ wg) @ (y @ wh).t()

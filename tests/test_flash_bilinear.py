@@ -1,0 +1,176 @@
+"""The fused B x B stage of the bilinear critic (csrc/mi_bilinear_flash.h) against the oracle, through the C ABI.
+
+bf16 mode tolerances (stated): against the oracle that rounds at the kernel's rounding points
+(``orc.bilinear_step_rounded``): loss 2e-3 * max(1, |S|max); every gradient 1e-2 * max|grad|.
+All tests need an MI355X:  python -m pytest tests -m gpu"""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import mi_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    from mutual_info_img_txt import _hip
+    _hip.load()
+    return torch.device("cuda:0")
+
+
+def _critic(dev, w):
+    from mutual_info_img_txt.model import BilinearCritic
+    c = BilinearCritic(w.shape[0], w.shape[1])
+    with torch.no_grad():
+        c.weight.copy_(w)
+    return c.to(dev)
+
+
+def _run(dev, x, y, w, sid, est, precision="bf16"):
+    from mutual_info_img_txt import _hip, mi_critics
+    critic = _critic(dev, w)
+    xl, yl = x.to(dev).requires_grad_(True), y.to(dev).requires_grad_(True)
+    loss, stats = mi_critics.fused_mi_bound(xl, yl, sid, critic, est, precision=precision, return_stats=True)
+    loss.sum().backward()
+    torch.cuda.synchronize()
+    return loss.detach().cpu(), _hip.stats_dict(stats), xl.grad.cpu(), yl.grad.cpu(), critic.weight.grad.cpu()
+
+
+def _rel(got, ref):
+    return float((got.double() - ref).abs().max()) / max(float(ref.abs().max()), 1e-30)
+
+
+@pytest.mark.parametrize("b,d", [(256, 512), (160, 256), (96, 128)])
+def test_flash_structure_exact(dev, b, d):
+    """S == 0 exactly (image features live in the first half of the width, text features in the second), so every
+    exponential is exactly 1: U_i and V_j are integer sums of rows, which pins the transposed-read operand maps, the
+    mask, the diagonal and the slab layout without any rounding in the way."""
+    gen = torch.Generator().manual_seed(b + d)
+    h = d // 2
+    x = torch.zeros(b, d)
+    y = torch.zeros(b, d)
+    x[:, :h] = torch.randint(-3, 4, (b, h), generator=gen).float()
+    y[:, h:] = torch.randint(-3, 4, (b, h), generator=gen).float()
+    w = torch.eye(d)
+    sid = torch.arange(b)
+    sid[5] = sid[77 % b]
+    sid[b - 1] = sid[b // 2]
+    sid[1] = sid[0]
+    loss, st, gx, gy, gw = _run(dev, x, y, w, sid, "infonce")
+    neg = orc.negative_mask(sid).double()
+    n_neg = int(neg.sum())
+    assert st["n_neg"] == n_neg
+    assert abs(float(loss) - math.log(n_neg)) < 1e-5
+    eye = torch.eye(b, dtype=torch.float64)
+    g = neg / n_neg - eye / b
+    dt = g @ y.double()          # exact small rationals; the kernel rounds dT to bf16 for the next product
+    dy = g.t() @ x.double()      # T == X here
+    np.testing.assert_allclose(gy.numpy(), dy.numpy(), rtol=2e-6, atol=1e-7)
+    np.testing.assert_allclose(gx.numpy(), dt.numpy(), rtol=4e-3, atol=1e-7)     # dX = bf16(dT) W^T, W = I
+    dw = x.double().t() @ orc.round_bf16(dt)
+    assert _rel(gw, dw) < 5e-3
+
+
+@pytest.mark.parametrize("b,dx,dy,est,dup", [(512, 512, 512, "infonce", True), (384, 200, 256, "dv", True),
+                                            (64, 128, 128, "dv", False), (64, 128, 128, "dv", True),
+                                            (256, 256, 256, "infonce", True), (1024, 512, 512, "dv", False),
+                                            (1024, 512, 512, "dv", True)])
+def test_flash_vs_rounded_oracle(dev, b, dx, dy, est, dup):
+    """BASELINE configs[0] (B=64, d=128, DV), configs[1] shape (B=256, d=256, InfoNCE), configs[2] bilinear leg (B=1024,
+    d=512, DV) and others, each also with SURVEY 8d's duplicated ids."""
+    gen = torch.Generator().manual_seed(1000 * b + dx)
+    x = torch.randn(b, dx, generator=gen)
+    y = torch.randn(b, dy, generator=gen)
+    w = torch.randn(dx, dy, generator=gen) * (0.25 / math.sqrt(dx))
+    sid = torch.arange(b)
+    if dup:
+        for n in range(max(b // 8, 4)):
+            sid[n] = n - (n % 2)
+        sid[b - 3] = sid[b // 3]
+    loss, st, gx, gy, gw = _run(dev, x, y, w, sid, est)
+    o = orc.bilinear_step_rounded(x, y, w, sid, est)
+    assert st["n_neg"] == int(orc.negative_mask(sid).sum())
+    sc = float(o["scores"].abs().max())
+    assert abs(float(loss.sum()) - float(o["loss"].sum())) < 2e-3 * max(sc, 1.0)
+    assert tuple(loss.shape) == ((1,) if est == "dv" else ())
+    for name, got, ref in (("dx", gx, o["dx"]), ("dy", gy, o["dy"]), ("dw", gw, o["dw"])):
+        err = _rel(got, ref)
+        assert err < 1e-2, (name, err)
+
+
+def test_flash_reference_point_rescale(dev):
+    """Force the rare branch (guide rule 26): the scores of the LAST streamed tiles are far above those of the first, so
+    every wave raises its reference point mid-sweep and rescales its accumulators."""
+    b, d = 512, 256
+    gen = torch.Generator().manual_seed(5)
+    x = torch.randn(b, d, generator=gen)
+    y = torch.randn(b, d, generator=gen)
+    w = torch.eye(d) * 0.35
+    # late rows of BOTH operands are scaled up: problem 0 streams the text rows, problem 1 the image rows
+    x[b - 64:] *= 3.0
+    y[b - 96:] *= 3.0
+    sid = torch.arange(b)
+    loss, st, gx, gy, gw = _run(dev, x, y, w, sid, "infonce")
+    o = orc.bilinear_step_rounded(x, y, w, sid, "infonce")
+    s = o["scores"]
+    early = float(s[:, :32][orc.negative_mask(sid)[:, :32]].max())
+    assert float(s.max()) - early > 30.0, "the case must cross the rescale threshold"
+    assert abs(float(loss) - float(o["loss"])) < 2e-3 * float(s.abs().max())
+    for name, got, ref in (("dx", gx, o["dx"]), ("dy", gy, o["dy"]), ("dw", gw, o["dw"])):
+        assert _rel(got, ref) < 1e-2, name
+
+
+def test_flash_no_negatives_and_single_block(dev):
+    """All ids equal: no negative pair at all -> the same non-finite loss as the reference (logsumexp of nothing)."""
+    b, d = 64, 128
+    gen = torch.Generator().manual_seed(9)
+    x, y = torch.randn(b, d, generator=gen), torch.randn(b, d, generator=gen)
+    w = torch.eye(d)
+    from mutual_info_img_txt import mi_critics
+    loss = mi_critics.fused_mi_bound(x.to(dev), y.to(dev), torch.zeros(b, dtype=torch.int64), _critic(dev, w), "infonce")
+    assert not math.isfinite(float(loss))
+
+
+@pytest.mark.parametrize("b,d,G", [(512, 256, 4), (256, 128, 2), (1024, 512, 8)])
+def test_flash_row_blocks_equal_full_batch(dev, b, d, G):
+    """Row-block sharding through the C ABI on one GPU: per-block forward records merged in block order give the full
+    batch's statistics; per-block backward outputs add up to the full batch's gradients."""
+    from mutual_info_img_txt.distributed import HipBilinearOps
+    from mutual_info_img_txt import _hip
+    gen = torch.Generator().manual_seed(b + G)
+    x = torch.randn(b, d, generator=gen)
+    y = torch.randn(b, d, generator=gen)
+    w = torch.randn(d, d, generator=gen) * (0.25 / math.sqrt(d))
+    sid = torch.arange(b)
+    sid[3] = sid[b - 5]
+    ops = HipBilinearOps()
+    xd, yd, wd, sd = x.to(dev), y.to(dev), w.to(dev), sid.to(dev)
+    br = b // G
+    recs, saved = [], []
+    for g in range(G):
+        rec, sv = ops.forward(xd[g * br:(g + 1) * br].contiguous(), yd, [wd], sd[g * br:(g + 1) * br].contiguous(), sd,
+                              g * br, 1, 1, True)
+        recs.append(rec)
+        saved.append(sv)
+    loss, stats = ops.merge(torch.stack(recs), b, 1)
+    go = torch.ones(1, device=dev)
+    gx = torch.empty_like(xd)
+    gy = torch.zeros_like(yd)
+    gw = torch.zeros_like(wd)
+    for g in range(G):
+        a, c, (e,) = ops.backward(saved[g], stats, go)
+        gx[g * br:(g + 1) * br] = a
+        gy += c
+        gw += e
+    o = orc.bilinear_step_rounded(x, y, w, sid, "infonce")
+    assert _hip.stats_dict(stats)["n_neg"] == int(orc.negative_mask(sid).sum())
+    assert abs(float(loss) - float(o["loss"])) < 2e-3 * float(o["scores"].abs().max())
+    for name, got, ref in (("dx", gx.cpu(), o["dx"]), ("dy", gy.cpu(), o["dy"]), ("dw", gw.cpu(), o["dw"])):
+        assert _rel(got, ref) < 1e-2, name
+    # one block's partial dY against the oracle's row-block form
+    ob = orc.bilinear_step_rounded(x, y, w, sid, "infonce", row_block=(br, 2 * br))
+    _, c1, _ = ops.backward(saved[1], stats, go)
+    assert _rel(c1.cpu(), ob["dy"]) < 1e-2
