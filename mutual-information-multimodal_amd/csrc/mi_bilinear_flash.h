@@ -36,6 +36,18 @@
 
 namespace mi {
 
+// diagnostic build only (make STAMPS=1): 16 s_memtime slots per workgroup, written by wave 0 (tools/diag/stamps_flash.py)
+#ifdef MI_STAMPS
+#define MI_FL_STAMP(slot)                                                                       \
+  do {                                                                                          \
+    __builtin_amdgcn_sched_barrier(0);                                                          \
+    if (threadIdx.x == 0 && g_stamps) g_stamps[(size_t)blockIdx.x * 16 + (slot)] = __builtin_amdgcn_s_memtime(); \
+    __builtin_amdgcn_sched_barrier(0);                                                          \
+  } while (0)
+#else
+#define MI_FL_STAMP(slot) do {} while (0)
+#endif
+
 constexpr int kFlRows = 128;     // stationary rows per workgroup
 constexpr int kFlBN = 32;        // streamed rows per tile
 constexpr int kFlStages = 4;     // LDS stages (three tiles in flight)
@@ -248,6 +260,7 @@ __global__ __launch_bounds__(256, 1) void bilinear_flash_kernel(FlashArgs args) 
   const bool wave_active = m_wave < P.m;                      // P.m % 32 == 0: a wave is all in or all out
   const int64_t gi = wave_active ? m_wave + r32 : r32;  // an idle wave re-reads rows 0..31; its outputs are dropped
 
+  MI_FL_STAMP(0);
   // ---- LDS-DMA pieces of this wave: piece q = PIECES * wave + i covers tile rows [q * RPP, (q + 1) * RPP)
   const char* kv_base = reinterpret_cast<const char*>(P.kv + tile0 * kFlBN * D);
   int src_off[C::PIECES];
@@ -308,19 +321,25 @@ __global__ __launch_bounds__(256, 1) void bilinear_flash_kernel(FlashArgs args) 
 
   // the Q loads, the id copy and the first tiles must have landed
   __syncthreads();  // hipcc drains vmcnt to 0 here (plain loads and LDS-DMA alike)
+  MI_FL_STAMP(1);
   // pin the register classes once: from here on only the asm MFMAs touch these values
   fl_static_for<0, C::NK>([&](auto KK) { fl_pin<(decltype(KK)::value < C::QA)>(qf[decltype(KK)::value]); });
   if constexpr (GRAD) fl_static_for<0, C::NT>([&](auto CT) { fl_pin_o<(decltype(CT)::value < C::OA)>(o[decltype(CT)::value]); });
 
   for (int t = 0; t < nt; ++t) {
+    const bool stamp_tile = t == nt / 2;
+    if (stamp_tile) MI_FL_STAMP(2);
+    if (t == nt / 2 + 1) MI_FL_STAMP(10);
     // ---- wait for tile t (own pieces), make every wave's pieces visible, refill the stage read one tile ago
     if (t > 0) {
       if (t + 2 < nt) fl_wait_vmcnt_barrier<2 * C::PIECES>();
       else if (t + 1 < nt) fl_wait_vmcnt_barrier<C::PIECES>();
       else fl_wait_vmcnt_barrier<0>();
     }
+    if (stamp_tile) MI_FL_STAMP(3);
     if (t + 3 < nt) issue_tile(t + 3);
     const int stage_off = (t & (kFlStages - 1)) * C::STAGE;
+    if (stamp_tile) MI_FL_STAMP(4);
 
     // ---- X = K Q^T: streamed rows in the registers, stationary rows on the lanes.  Fragment reads run one chunk of
     // four 16-deep steps ahead of the MFMAs; the scheduling fences bound the fragments in flight.
@@ -351,6 +370,7 @@ __global__ __launch_bounds__(256, 1) void bilinear_flash_kernel(FlashArgs args) 
       });
       fl_mfma_drain(s);
     }
+    if (stamp_tile) MI_FL_STAMP(5);
 
     // ---- mask, positives, reference point, exponentials
     const int64_t* sl = reinterpret_cast<const int64_t*>(smem + C::SID_OFF) + t * kFlBN + 4 * half;
@@ -387,6 +407,7 @@ __global__ __launch_bounds__(256, 1) void bilinear_flash_kernel(FlashArgs args) 
       lsum += s[r];
     }
 
+    if (stamp_tile) MI_FL_STAMP(6);
     if constexpr (GRAD) {
       // ---- O += P (A operand straight from the accumulator layout) x V (transposed reads of the same tile)
       bf16x8 pf[2];
@@ -412,7 +433,9 @@ __global__ __launch_bounds__(256, 1) void bilinear_flash_kernel(FlashArgs args) 
                                                                        vf[c & 1]);
       });
     }
+    if (stamp_tile) MI_FL_STAMP(7);
   }
+  MI_FL_STAMP(8);
 
   // ---- records and partial sums
   lsum = wave_sum(lsum);
@@ -435,6 +458,7 @@ __global__ __launch_bounds__(256, 1) void bilinear_flash_kernel(FlashArgs args) 
         }
     }
   }
+  MI_FL_STAMP(9);
 }
 
 // ------------------------------------------------------------------------------------------------ slab reduce
@@ -587,6 +611,9 @@ static inline FlashPlan flash_plan(int64_t br, int64_t b, int64_t d) {
 template <int D, bool GRAD>
 static inline int launch_flash_t(const FlashArgs& a, unsigned grid, hipStream_t st, const char* what) {
   MI_SET_DYN_SMEM((bilinear_flash_kernel<D, GRAD>), FlashCfg<D>::SMEM, "hipFuncSetAttribute(bilinear_flash_kernel)");
+#ifdef MI_STAMPS
+  stamp_select(what, st);
+#endif
   {
     ProfScope prof_(what, st);
     hipLaunchKernelGGL((bilinear_flash_kernel<D, GRAD>), dim3(grid), dim3(256), FlashCfg<D>::SMEM, st, a);

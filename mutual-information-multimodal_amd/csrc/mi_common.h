@@ -7,6 +7,9 @@
 #include <string.h>
 #include <stdlib.h>
 
+#include <atomic>
+#include <mutex>
+
 #include "../../include/mi_critic.h"
 
 namespace mi {
@@ -158,17 +161,36 @@ __device__ __forceinline__ int pair_kind(int64_t gi, int64_t gj, int64_t sid_i, 
   return sid_i != sid_j ? 2 : 0;
 }
 
-// Raise a kernel's dynamic-LDS limit, once per size: hipFuncSetAttribute is host-side state, and calling it on every
-// launch also put such calls inside stream captures (the concat-MLP step could not be captured into a hipGraph).
-#define MI_SET_DYN_SMEM(fn, bytes, what)                                                                       \
-  do {                                                                                                         \
-    static size_t mi_cur_smem_ = 0;                                                                            \
-    if ((size_t)(bytes) > mi_cur_smem_) {                                                                      \
-      hipError_t mi_e_ = hipFuncSetAttribute((const void*)(fn), hipFuncAttributeMaxDynamicSharedMemorySize,    \
-                                             (int)(bytes));                                                    \
-      if (mi_e_ != hipSuccess) return hip_fail(mi_e_, what);                                                   \
-      mi_cur_smem_ = (size_t)(bytes);                                                                          \
-    }                                                                                                          \
+// Raise a kernel's dynamic-LDS limit, once per (device, size): hipFuncSetAttribute is host-side state, and calling it on
+// every launch also put such calls inside stream captures (the concat-MLP step could not be captured into a hipGraph).
+// The cache is per launch site and per device and is safe to use from several host threads (autograd runs the backward
+// on another thread than the forward): an atomic high-water mark per device, raised under a mutex.
+struct DynSmemCache {
+  static constexpr int kMaxDevices = 16;
+  std::atomic<size_t> cur[kMaxDevices];
+  std::mutex mu;
+  DynSmemCache() {
+    for (auto& c : cur) c.store(0, std::memory_order_relaxed);
+  }
+  // returns hipSuccess when the limit of `fn` on the current device is >= bytes afterwards
+  hipError_t ensure(const void* fn, size_t bytes) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev < 0 || dev >= kMaxDevices) return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (cur[dev].load(std::memory_order_acquire) >= bytes) return hipSuccess;
+    std::lock_guard<std::mutex> lock(mu);
+    if (cur[dev].load(std::memory_order_relaxed) >= bytes) return hipSuccess;
+    e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e == hipSuccess) cur[dev].store(bytes, std::memory_order_release);
+    return e;
+  }
+};
+#define MI_SET_DYN_SMEM(fn, bytes, what)                                                  \
+  do {                                                                                    \
+    static ::mi::DynSmemCache mi_smem_cache_;                                             \
+    hipError_t mi_e_ = mi_smem_cache_.ensure((const void*)(fn), (size_t)(bytes));         \
+    if (mi_e_ != hipSuccess) return hip_fail(mi_e_, what);                                \
   } while (0)
 
 // XCD affinity for 1-D grids (speed only, never correctness: guide T1 / section 6 G16).  Workgroups are dealt

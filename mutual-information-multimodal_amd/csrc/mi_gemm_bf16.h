@@ -1050,31 +1050,16 @@ static inline int launch_gemm_bf16(const GemmBf16Args& args_in, int n_splits, co
     if (args.p[1].n > nn) nn = args.p[1].n;
   }
   if (mm <= 0 || nn <= 0) return MI_OK;
-  static bool attr_set = false;  // per Epi instantiation
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_kernel<Epi>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)kG2Smem);
-    if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(gemm_bf16_kernel)");
-    e = hipFuncSetAttribute((const void*)gemm_bf16_glds_kernel<Epi>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)kG2SmemGlds);
-    if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(gemm_bf16_glds_kernel)");
-    if constexpr (!Epi::kReducesPartial) {
-      e = hipFuncSetAttribute((const void*)gemm_bf16_pipe_kernel<PipeCfg128, Epi>,
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)PipeCfg128::SMEM);
-      if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(gemm_bf16_pipe_kernel 128)");
-    }
-    attr_set = true;
-  }
+  // per Epi instantiation, per device, thread-safe (mi_common.h)
+  MI_SET_DYN_SMEM((gemm_bf16_kernel<Epi>), kG2Smem, "hipFuncSetAttribute(gemm_bf16_kernel)");
+  MI_SET_DYN_SMEM((gemm_bf16_glds_kernel<Epi>), kG2SmemGlds, "hipFuncSetAttribute(gemm_bf16_glds_kernel)");
+  if constexpr (!Epi::kReducesPartial)
+    MI_SET_DYN_SMEM((gemm_bf16_pipe_kernel<PipeCfg128, Epi>), PipeCfg128::SMEM,
+                    "hipFuncSetAttribute(gemm_bf16_pipe_kernel 128)");
   bool dma_ok = args.k_chunk % kG2KT == 0 || n_splits == 1;
   for (int q = 0; q < args.n_problems; ++q) dma_ok = dma_ok && args.p[q].k % kG2KT == 0 && args.p[q].k > 0;
   if (dma_ok && args.n_problems == 1 && n_splits == 1 && gemm_bf16_use_big(mm, nn, args.p[0].k)) {
-    static bool big_attr_set = false;  // per Epi instantiation
-    if (!big_attr_set) {
-      hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_big_kernel<Epi>,
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)kG2SmemBig);
-      if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(gemm_bf16_big_kernel)");
-      big_attr_set = true;
-    }
+    MI_SET_DYN_SMEM((gemm_bf16_big_kernel<Epi>), kG2SmemBig, "hipFuncSetAttribute(gemm_bf16_big_kernel)");
     dim3 grid((unsigned)((nn + 255) / 256), (unsigned)((mm + 255) / 256), 1);
     xcd_pick_blocks(grid.y, grid.x, 256, args.p[0].k, 1, args.xcd_gy, args.xcd_gx);
     MI_STAMP_SELECT(what, st);
@@ -1127,13 +1112,7 @@ static inline int launch_gemm_bf16_flat(const GemmBf16Args& args_in, const int (
     total = (total + 7) / 8 * 8;  // keep every problem's first workgroup on XCD 0 (ids in the gap return at once)
   }
   if (!ok) return MI_EINVAL;
-  static bool attr_set = false;  // per Epi instantiation
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_glds_kernel<Epi>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)kG2SmemGlds);
-    if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(gemm_bf16_glds_kernel)");
-    attr_set = true;
-  }
+  MI_SET_DYN_SMEM((gemm_bf16_glds_kernel<Epi>), kG2SmemGlds, "hipFuncSetAttribute(gemm_bf16_glds_kernel)");
   args.flat = 1;
   args.xcd_gy = args.xcd_gx = 0;
   args.k_chunk = 0;

@@ -86,8 +86,19 @@ def check(rc: int, what: str) -> None:
     raise MiCriticError(f"{what}: {msg} (code {rc})")
 
 
-def stream_ptr() -> int:
-    return torch.cuda.current_stream().cuda_stream
+def stream_ptr(device=None) -> int:
+    """hipStream_t of torch's current stream on ``device`` (default: the current device)."""
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def call(name: str, device, *args) -> None:
+    """Run the C-ABI entry point ``name(*args, stream)`` with ``device`` current and torch's current stream of THAT
+    device as the trailing stream argument (the library never sets the device itself: tensors on cuda:1 while cuda:0 is
+    current would otherwise be launched on the wrong device's stream).  Raises on a non-zero status."""
+    lib = load()
+    with torch.cuda.device(device):
+        rc = getattr(lib, name)(*args, torch.cuda.current_stream(device).cuda_stream)
+    check(rc, name)
 
 
 def ptr(t: Optional[torch.Tensor]) -> Optional[int]:

@@ -40,11 +40,11 @@ class HipBilinearOps:
         stats = _hip.new_stats(dev)
         loss = torch.empty(1, dtype=torch.float32, device=dev)
         record = torch.empty(_hip.RECORD_FLOATS, dtype=torch.float32, device=dev)
-        _hip.check(lib.mi_bilinear_fwd(x.data_ptr(), y_all.data_ptr(), w.data_ptr(), sid_rows.data_ptr(),
+        _hip.call("mi_bilinear_fwd", dev, x.data_ptr(), y_all.data_ptr(), w.data_ptr(), sid_rows.data_ptr(),
                                        sid_all.data_ptr(), br, b, row_offset, dx, dy, estimator, precision,
                                        int(bool(need_grad)), loss.data_ptr(), stats.data_ptr(), record.data_ptr(), None,
                                        ws.data_ptr(),
-                                       ws.numel(), _hip.stream_ptr()), "mi_bilinear_fwd")
+                                       ws.numel())
         return record, (x, y_all, w, sid_rows, sid_all, row_offset, precision, ws)
 
     def merge(self, records, n_pos, estimator):
@@ -52,8 +52,8 @@ class HipBilinearOps:
         dev = records.device
         stats = _hip.new_stats(dev)
         loss = torch.empty(1, dtype=torch.float32, device=dev)
-        _hip.check(lib.mi_merge_partials(records.data_ptr(), records.shape[0], n_pos, estimator, loss.data_ptr(),
-                                         stats.data_ptr(), _hip.stream_ptr()), "mi_merge_partials")
+        _hip.call("mi_merge_partials", dev, records.data_ptr(), records.shape[0], n_pos, estimator, loss.data_ptr(),
+                                         stats.data_ptr())
         return loss, stats
 
     def backward(self, saved, stats, grad_out):
@@ -62,10 +62,10 @@ class HipBilinearOps:
         br, dx = x.shape
         b, dy = y_all.shape
         gx, gy, gw = torch.empty_like(x), torch.empty_like(y_all), torch.empty_like(w)
-        _hip.check(lib.mi_bilinear_bwd(x.data_ptr(), y_all.data_ptr(), w.data_ptr(), sid_rows.data_ptr(),
+        _hip.call("mi_bilinear_bwd", x.device, x.data_ptr(), y_all.data_ptr(), w.data_ptr(), sid_rows.data_ptr(),
                                        sid_all.data_ptr(), br, b, row_offset, dx, dy, precision, stats.data_ptr(),
                                        grad_out.data_ptr(), gx.data_ptr(), gy.data_ptr(), gw.data_ptr(), ws.data_ptr(),
-                                       ws.numel(), 1, _hip.stream_ptr()), "mi_bilinear_bwd")
+                                       ws.numel(), 1)
         return gx, gy, [gw]
 
 
@@ -84,11 +84,10 @@ class HipConcatMlpOps:
         loss = torch.empty(1, dtype=torch.float32, device=dev)
         record = torch.empty(_hip.RECORD_FLOATS, dtype=torch.float32, device=dev)
         scores = torch.empty(br, b, dtype=torch.float32, device=dev)
-        _hip.check(lib.mi_concat_mlp_fwd(x.data_ptr(), y_all.data_ptr(), *[p.data_ptr() for p in params],
+        _hip.call("mi_concat_mlp_fwd", dev, x.data_ptr(), y_all.data_ptr(), *[p.data_ptr() for p in params],
                                          sid_rows.data_ptr(), sid_all.data_ptr(), br, b, row_offset, dx, dy, h1, h2,
                                          estimator, precision, int(need_grad), loss.data_ptr(), stats.data_ptr(),
-                                         record.data_ptr(), scores.data_ptr(), ws.data_ptr(), ws.numel(),
-                                         _hip.stream_ptr()), "mi_concat_mlp_fwd")
+                                         record.data_ptr(), scores.data_ptr(), ws.data_ptr(), ws.numel())
         return record, (x, y_all, list(params), sid_rows, sid_all, row_offset, precision, scores, ws)
 
     merge = HipBilinearOps.merge
@@ -101,11 +100,11 @@ class HipConcatMlpOps:
         h1, h2 = params[0].shape[0], params[2].shape[0]
         gx, gy = torch.empty_like(x), torch.empty_like(y_all)
         gp = [torch.empty_like(p) for p in params]
-        _hip.check(lib.mi_concat_mlp_bwd(x.data_ptr(), y_all.data_ptr(), *[p.data_ptr() for p in params],
+        _hip.call("mi_concat_mlp_bwd", x.device, x.data_ptr(), y_all.data_ptr(), *[p.data_ptr() for p in params],
                                          sid_rows.data_ptr(), sid_all.data_ptr(), br, b, row_offset, dx, dy, h1, h2,
                                          precision, stats.data_ptr(), grad_out.data_ptr(), scores.data_ptr(),
                                          gx.data_ptr(), gy.data_ptr(), *[g.data_ptr() for g in gp], ws.data_ptr(),
-                                         ws.numel(), _hip.stream_ptr()), "mi_concat_mlp_bwd")
+                                         ws.numel())
         return gx, gy, gp
 
 

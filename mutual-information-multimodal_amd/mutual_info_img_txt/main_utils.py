@@ -35,19 +35,18 @@ class _CreatePairsFn(torch.autograd.Function):
         b, d_img = img.shape
         d_txt = txt.shape[1]
         dev = img.device
-        st = _hip.stream_ptr()
         ws = _hip.workspace(lib.mi_pair_index_workspace_bytes(b), dev)
         cap = b * b
         pair_i = torch.empty(cap, dtype=torch.int32, device=dev)
         pair_j = torch.empty(cap, dtype=torch.int32, device=dev)
         n_dev = torch.empty(1, dtype=torch.int64, device=dev)
         rowpos = torch.empty(max(b * (b - 1), 1), dtype=torch.int32, device=dev)
-        _hip.check(lib.mi_pair_index(sid.data_ptr(), b, pair_i.data_ptr(), pair_j.data_ptr(), cap, n_dev.data_ptr(),
-                                     rowpos.data_ptr(), ws.data_ptr(), ws.numel(), st), "mi_pair_index")
+        _hip.call("mi_pair_index", dev, sid.data_ptr(), b, pair_i.data_ptr(), pair_j.data_ptr(), cap, n_dev.data_ptr(),
+                                     rowpos.data_ptr(), ws.data_ptr(), ws.numel())
         n_rows = int(n_dev.item())  # the output shape is data dependent (host sync, as any nonzero()-like op)
         out = torch.empty(n_rows, d_img + d_txt, dtype=torch.float32, device=dev)
-        _hip.check(lib.mi_create_pairs(img.data_ptr(), txt.data_ptr(), pair_i.data_ptr(), pair_j.data_ptr(), n_rows,
-                                       d_img, d_txt, out.data_ptr(), st), "mi_create_pairs")
+        _hip.call("mi_create_pairs", dev, img.data_ptr(), txt.data_ptr(), pair_i.data_ptr(), pair_j.data_ptr(), n_rows,
+                                       d_img, d_txt, out.data_ptr())
         ctx.save_for_backward(rowpos)
         ctx.dims = (b, d_img, d_txt)
         ctx.pair_index = (pair_i[:n_rows], pair_j[:n_rows])
@@ -61,8 +60,8 @@ class _CreatePairsFn(torch.autograd.Function):
         g = _hip.f32c(grad_out, "grad of mi_input")
         gi = torch.empty(b, d_img, dtype=torch.float32, device=g.device)
         gt = torch.empty(b, d_txt, dtype=torch.float32, device=g.device)
-        _hip.check(lib.mi_create_pairs_bwd(g.data_ptr(), rowpos.data_ptr(), b, d_img, d_txt, gi.data_ptr(),
-                                           gt.data_ptr(), _hip.stream_ptr()), "mi_create_pairs_bwd")
+        _hip.call("mi_create_pairs_bwd", g.device, g.data_ptr(), rowpos.data_ptr(), b, d_img, d_txt, gi.data_ptr(),
+                                           gt.data_ptr())
         return gi, gt, None
 
 
@@ -76,8 +75,8 @@ def pair_index(study_id: Sequence, device):
     pair_i = torch.empty(cap, dtype=torch.int32, device=sid.device)
     pair_j = torch.empty(cap, dtype=torch.int32, device=sid.device)
     n_dev = torch.empty(1, dtype=torch.int64, device=sid.device)
-    _hip.check(lib.mi_pair_index(sid.data_ptr(), b, pair_i.data_ptr(), pair_j.data_ptr(), cap, n_dev.data_ptr(), None,
-                                 ws.data_ptr(), ws.numel(), _hip.stream_ptr()), "mi_pair_index")
+    _hip.call("mi_pair_index", sid.device, sid.data_ptr(), b, pair_i.data_ptr(), pair_j.data_ptr(), cap, n_dev.data_ptr(), None,
+                                 ws.data_ptr(), ws.numel())
     n = int(n_dev.item())
     return pair_i[:n], pair_j[:n]
 

@@ -69,8 +69,8 @@ class _BoundFn(torch.autograd.Function):
         ws = _hip.workspace(lib.mi_bound_workspace_bytes(n), dev)
         stats = _hip.new_stats(dev)
         loss = torch.empty(1, dtype=torch.float32, device=dev)
-        _hip.check(lib.mi_bound_fwd(flat.data_ptr(), n, int(pos_size), estimator, loss.data_ptr(), stats.data_ptr(),
-                                    ws.data_ptr(), ws.numel(), _hip.stream_ptr()), "mi_bound_fwd")
+        _hip.call("mi_bound_fwd", dev, flat.data_ptr(), n, int(pos_size), estimator, loss.data_ptr(), stats.data_ptr(),
+                                    ws.data_ptr(), ws.numel())
         ctx.save_for_backward(flat, stats)
         ctx.pos_size = int(pos_size)
         ctx.in_shape = logits.shape
@@ -82,8 +82,8 @@ class _BoundFn(torch.autograd.Function):
         flat, stats = ctx.saved_tensors
         go = _grad_scalar(grad_loss)
         grad = torch.empty_like(flat)
-        _hip.check(lib.mi_bound_bwd(flat.data_ptr(), flat.numel(), ctx.pos_size, stats.data_ptr(), go.data_ptr(),
-                                    grad.data_ptr(), _hip.stream_ptr()), "mi_bound_bwd")
+        _hip.call("mi_bound_bwd", flat.device, flat.data_ptr(), flat.numel(), ctx.pos_size, stats.data_ptr(), go.data_ptr(),
+                                    grad.data_ptr())
         return grad.reshape(ctx.in_shape), None, None
 
 
@@ -123,9 +123,8 @@ class _MatrixBoundFn(torch.autograd.Function):
         ws = _hip.workspace(lib.mi_matrix_bound_workspace_bytes(b), dev)
         stats = _hip.new_stats(dev)
         loss = torch.empty(1, dtype=torch.float32, device=dev)
-        _hip.check(lib.mi_matrix_bound_fwd(s.data_ptr(), sid.data_ptr(), b, estimator, loss.data_ptr(),
-                                           stats.data_ptr(), ws.data_ptr(), ws.numel(), _hip.stream_ptr()),
-                   "mi_matrix_bound_fwd")
+        _hip.call("mi_matrix_bound_fwd", dev, s.data_ptr(), sid.data_ptr(), b, estimator, loss.data_ptr(),
+                                           stats.data_ptr(), ws.data_ptr(), ws.numel())
         ctx.save_for_backward(s, sid, stats)
         return loss
 
@@ -135,8 +134,8 @@ class _MatrixBoundFn(torch.autograd.Function):
         s, sid, stats = ctx.saved_tensors
         go = _grad_scalar(grad_loss)
         grad = torch.empty_like(s)
-        _hip.check(lib.mi_matrix_bound_bwd(s.data_ptr(), sid.data_ptr(), s.shape[0], stats.data_ptr(), go.data_ptr(),
-                                           grad.data_ptr(), _hip.stream_ptr()), "mi_matrix_bound_bwd")
+        _hip.call("mi_matrix_bound_bwd", s.device, s.data_ptr(), sid.data_ptr(), s.shape[0], stats.data_ptr(), go.data_ptr(),
+                                           grad.data_ptr())
         return grad, None, None
 
 
@@ -175,10 +174,9 @@ class BilinearCriticFn(torch.autograd.Function):
         record = torch.empty(_hip.RECORD_FLOATS, dtype=torch.float32, device=dev)
         scores = torch.empty(b, b, dtype=torch.float32, device=dev) if want_scores else None
         need_grad = 1 if any(ctx.needs_input_grad[:3]) else 0
-        _hip.check(lib.mi_bilinear_fwd(x.data_ptr(), y.data_ptr(), _hip.ptr(w), sid.data_ptr(), sid.data_ptr(), b, b, 0,
+        _hip.call("mi_bilinear_fwd", dev, x.data_ptr(), y.data_ptr(), _hip.ptr(w), sid.data_ptr(), sid.data_ptr(), b, b, 0,
                                        dx, dy, estimator, precision, need_grad, loss.data_ptr(), stats.data_ptr(),
-                                       record.data_ptr(), _hip.ptr(scores), ws.data_ptr(), ws.numel(),
-                                       _hip.stream_ptr()), "mi_bilinear_fwd")
+                                       record.data_ptr(), _hip.ptr(scores), ws.data_ptr(), ws.numel())
         ctx.save_for_backward(x, y, sid, stats, ws, *([] if w is None else [w]))
         ctx.precision = precision
         ctx.mark_non_differentiable(stats)
@@ -197,10 +195,9 @@ class BilinearCriticFn(torch.autograd.Function):
         go = _grad_scalar(grad_loss)
         gx, gy = torch.empty_like(x), torch.empty_like(y)
         gw = None if w is None else torch.empty_like(w)
-        _hip.check(lib.mi_bilinear_bwd(x.data_ptr(), y.data_ptr(), _hip.ptr(w), sid.data_ptr(), sid.data_ptr(), b, b, 0,
+        _hip.call("mi_bilinear_bwd", x.device, x.data_ptr(), y.data_ptr(), _hip.ptr(w), sid.data_ptr(), sid.data_ptr(), b, b, 0,
                                        dx, dy, ctx.precision, stats.data_ptr(), go.data_ptr(), gx.data_ptr(),
-                                       gy.data_ptr(), _hip.ptr(gw), ws.data_ptr(), ws.numel(), 1, _hip.stream_ptr()),
-                   "mi_bilinear_bwd")
+                                       gy.data_ptr(), _hip.ptr(gw), ws.data_ptr(), ws.numel(), 1)
         return gx, gy, gw, None, None, None, None
 
 
@@ -223,10 +220,10 @@ class ConcatMlpCriticFn(torch.autograd.Function):
         loss = torch.empty(1, dtype=torch.float32, device=dev)
         record = torch.empty(_hip.RECORD_FLOATS, dtype=torch.float32, device=dev)
         scores = torch.empty(b, b, dtype=torch.float32, device=dev)
-        _hip.check(lib.mi_concat_mlp_fwd(x.data_ptr(), y.data_ptr(), *[p.data_ptr() for p in params], sid.data_ptr(),
+        _hip.call("mi_concat_mlp_fwd", dev, x.data_ptr(), y.data_ptr(), *[p.data_ptr() for p in params], sid.data_ptr(),
                                          sid.data_ptr(), b, b, 0, dx, dy, h1, h2, estimator, precision, need_grad,
                                          loss.data_ptr(), stats.data_ptr(), record.data_ptr(), scores.data_ptr(),
-                                         ws.data_ptr(), ws.numel(), _hip.stream_ptr()), "mi_concat_mlp_fwd")
+                                         ws.data_ptr(), ws.numel())
         ctx.save_for_backward(x, y, *params, sid, stats, scores, ws)
         ctx.precision = precision
         ctx.mark_non_differentiable(stats, scores)
@@ -241,11 +238,10 @@ class ConcatMlpCriticFn(torch.autograd.Function):
         h1, h2 = w1.shape[0], w2.shape[0]
         go = _grad_scalar(grad_loss)
         grads = [torch.empty_like(t) for t in (x, y, w1, b1, w2, b2, w3, b3)]
-        _hip.check(lib.mi_concat_mlp_bwd(x.data_ptr(), y.data_ptr(), w1.data_ptr(), b1.data_ptr(), w2.data_ptr(),
+        _hip.call("mi_concat_mlp_bwd", x.device, x.data_ptr(), y.data_ptr(), w1.data_ptr(), b1.data_ptr(), w2.data_ptr(),
                                          b2.data_ptr(), w3.data_ptr(), b3.data_ptr(), sid.data_ptr(), sid.data_ptr(), b,
                                          b, 0, dx, dy, h1, h2, ctx.precision, stats.data_ptr(), go.data_ptr(),
-                                         scores.data_ptr(), *[g.data_ptr() for g in grads], ws.data_ptr(), ws.numel(),
-                                         _hip.stream_ptr()), "mi_concat_mlp_bwd")
+                                         scores.data_ptr(), *[g.data_ptr() for g in grads], ws.data_ptr(), ws.numel())
         return (*grads, None, None, None, None)
 
 

@@ -525,7 +525,7 @@ def test_row_block_sharding_equals_full_batch(dev, critic, precision, b, d, G):
     lg, sg, gxg, gyg, gpg = run(G)
     assert s1["n_neg"] == sg["n_neg"] and s1["n_pos"] == sg["n_pos"] == b
     assert abs(float(l1) - float(lg)) < 2e-6 * max(1.0, abs(float(l1)))
-    tol = 2e-5 if precision == "f32" else (2e-3 if b < 1024 else 4e-3)  # bf16: dT is rounded per row block
+    tol = 2e-5 if precision == "f32" else 1e-2  # bf16: P is rounded against per-wave reference points, dT per row block
     for a, c in [(gx1, gxg), (gy1, gyg)] + list(zip(gp1, gpg)):
         scale = max(float(a.abs().max()), 1e-12)
         assert float((a - c).abs().max()) <= tol * scale + 1e-7

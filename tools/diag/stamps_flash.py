@@ -1,0 +1,55 @@
+"""Diagnostic: s_memtime stamps of the fused bilinear kernel (needs lib_stamps/, `make STAMPS=1`):
+   MI_STAMP_KERNEL="fused S" python tools/diag/stamps_flash.py"""
+import os, sys
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..")
+os.environ["MI_CRITIC_LIB"] = os.path.join(ROOT, "mutual-information-multimodal_amd", "lib_stamps", "libmi_critic_hip.so")
+os.environ.setdefault("MI_STAMP_KERNEL", "fused S")
+sys.path.insert(0, os.path.join(ROOT, "mutual-information-multimodal_amd"))
+sys.path.insert(0, ROOT)
+import ctypes
+import numpy as np
+import torch
+from mutual_info_img_txt import mi_critics, _hip
+from mutual_info_img_txt.model import BilinearCritic
+
+dev = torch.device("cuda:0")
+b, d = int(os.environ.get("B", 4096)), int(os.environ.get("D", 512))
+x = torch.randn(b, d, device=dev, requires_grad=True)
+y = torch.randn(b, d, device=dev, requires_grad=True)
+sid = torch.arange(b, device=dev)
+critic = BilinearCritic(d, d).to(dev)
+lib = _hip.load()
+lib.mi_debug_set_stamps.argtypes = [ctypes.c_void_p]
+buf = torch.zeros(8192 * 16, dtype=torch.int64, device=dev)
+lib.mi_debug_set_stamps(buf.data_ptr())
+
+def step():
+    x.grad = None; y.grad = None
+    for p in critic.parameters(): p.grad = None
+    loss = mi_critics.fused_mi_bound(x, y, sid, critic, "infonce", precision="bf16")
+    loss.sum().backward()
+
+for _ in range(5): step()
+torch.cuda.synchronize()
+buf.zero_()
+step()
+torch.cuda.synchronize()
+s = buf.cpu().numpy().reshape(-1, 16)
+s = s[s[:, 0] != 0]
+print("workgroups stamped:", len(s))
+t0 = s[:, 0].min()
+def seg(name, a, c):
+    d_ = s[:, c] - s[:, a]
+    print(f"{name:34s} median {np.median(d_):9.0f}  p10 {np.percentile(d_,10):9.0f}  p90 {np.percentile(d_,90):9.0f}")
+seg("prologue (entry -> first barrier)", 0, 1)
+seg("whole loop", 1, 8)
+seg("epilogue (records + slab stores)", 8, 9)
+seg("whole workgroup", 0, 9)
+print("--- one tile (t = nt/2)")
+seg("wait + barrier", 2, 3)
+seg("LDS-DMA issue of tile t+3", 3, 4)
+seg("S phase (32 MFMAs + drain)", 4, 5)
+seg("mask / max / exp", 5, 6)
+seg("PV phase (32 MFMAs)", 6, 7)
+seg("tile period (top -> next top)", 2, 10)
+print(f"start skew: median {np.median(s[:,0]-t0):.0f} max {np.max(s[:,0]-t0):.0f}; kernel span {s[:,9].max()-t0} ticks")
