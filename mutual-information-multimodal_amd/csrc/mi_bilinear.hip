@@ -39,6 +39,7 @@ struct BilinearPlan {
   FlashPlan fl;
   float* fl_slab[2];
   Partial* fl_rec[2];
+  unsigned char* fl_dup[2];  // equal-id flags per 32 x 32 block: [br / 32][b / 32] and its transpose
   size_t bytes;
 };
 
@@ -65,6 +66,7 @@ static BilinearPlan plan_bilinear(Workspace& ws, int64_t br, int64_t b, int64_t 
   for (int q = 0; q < 2; ++q) {
     p.fl_rec[q] = p.fl.ok ? ws.take<Partial>(p.fl.n_rec[q]) : nullptr;
     p.fl_slab[q] = p.fl.ok ? ws.take<float>(p.fl.slab_floats[q]) : nullptr;
+    p.fl_dup[q] = p.fl.ok ? ws.take<unsigned char>((br / 32) * (b / 32)) : nullptr;
   }
   // backward
   p.dt = ws.take<float>(br * dy);
@@ -134,10 +136,12 @@ static int bilinear_bwd_small(int64_t br, int64_t dx, int64_t dy, float* grad_x,
 static int flash_stage(const int64_t* sid_rows, const int64_t* sid_cols, int64_t br, int64_t b, int64_t row_offset,
                        int64_t dy, bool grad, const BilinearPlan& p, hipStream_t st) {
   FlashArgs a{};
+  int rc = launch_flash_dup_flags(sid_rows, sid_cols, br, b, p.fl_dup[0], p.fl_dup[1], st);
+  if (rc) return rc;
   a.p[0] = FlashProblem{p.tb, p.yb, sid_rows, sid_cols, br, b, row_offset, p.fl.n_rb[0], p.fl.n_split[0],
-                        p.fl.tiles_per_split[0], p.fl_slab[0], p.fl_rec[0]};
+                        p.fl.tiles_per_split[0], p.fl_dup[0], p.fl_slab[0], p.fl_rec[0]};
   a.p[1] = FlashProblem{p.yb, p.tb, sid_cols, sid_rows, b, br, -row_offset, p.fl.n_rb[1], p.fl.n_split[1],
-                        p.fl.tiles_per_split[1], p.fl_slab[1], p.fl_rec[1]};
+                        p.fl.tiles_per_split[1], p.fl_dup[1], p.fl_slab[1], p.fl_rec[1]};
   a.n_problems = grad ? 2 : 1;
   return launch_flash(a, dy, grad, st, grad ? "bilinear fused S | P Y | P^T T" : "bilinear fused S + LSE");
 }

@@ -64,6 +64,7 @@ struct FlashProblem {
   int n_rb;               // row blocks of 128 stationary rows
   int n_split;            // workgroups per row block
   int tiles_per_split;
+  const unsigned char* dup;  // [m / 32][n / 32]: 1 iff the 32 x 32 block holds a pair with equal study ids
   float* slab;            // [n_split][n_rb][4 waves][32 * D] partial sums in accumulator order
   Partial* rec;           // [n_split][n_rb][4]
 };
@@ -84,8 +85,8 @@ struct FlashCfg {
   static constexpr int PIECES = STAGE / 1024 / 4;      // LDS-DMA pieces per wave and tile
   static constexpr int SID_OFF = kFlStages * STAGE;    // streamed study ids
   static constexpr size_t SMEM = (size_t)SID_OFF + (size_t)kFlMaxTilesPerSplit * kFlBN * 8;
-  static constexpr int QA = NK / 2;                    // stationary fragments [0, QA) in accumulator registers
-  static constexpr int OA = NT >= 16 ? 12 : (NT >= 8 ? 4 : 0);  // output tiles [0, OA) in accumulator registers
+  static constexpr int QA = NT >= 16 ? NK / 2 : 0;     // stationary fragments [0, QA) in accumulator registers
+  static constexpr int OA = NT >= 16 ? 12 : NT;        // output tiles [0, OA) in accumulator registers
   static_assert(D == 128 || D == 256 || D == 512, "unsupported embedding width");
 };
 
@@ -108,6 +109,24 @@ __device__ __forceinline__ float wave_max_uniform(float v) {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
+// one LDS-DMA piece: 64 lanes x 16 bytes from sbase + voff (per lane) to the LDS byte address lds_addr + 16 * lane.
+// M0 carries the LDS address and is compiler-reserved: saved and restored inside the statement (guide 5.7).
+__device__ __forceinline__ void fl_dma16(unsigned voff, const void* sbase, unsigned lds_addr) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(voff), "s"(sbase), "s"(lds_addr)
+               : "memory");
+}
+
+// max of three without the canonicalising v_max(x, x) hipcc puts in front of fmaxf on MFMA outputs (NaNs propagate to
+// the loss either way: a NaN score makes the log-sum-exp NaN)
+__device__ __forceinline__ float fl_max3(float a, float b, float c) {
+  float d;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  return d;
+}
+
 template <int N>
 __device__ __forceinline__ void fl_wait_vmcnt_barrier() {
   asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
@@ -127,77 +146,120 @@ __device__ __forceinline__ void fl_static_for(F&& f) {
 // 256 output accumulators in the second, spilled all 128 registers of stationary rows to scratch (215 spills, reloaded
 // every tile).  The hardware takes A, B and C / D from either file, so the split is made by hand: output tiles
 // [0, OA) and stationary fragments [0, QA) live in accumulator registers, the rest in VGPRs.
-// Hazards the compiler cannot see inside an asm statement are covered by hand (guide section 5.7 item 2):
-//   * a VALU-written operand needs two wait states before the MFMA reads it: FIRST = true puts an s_nop 1 in front;
+//
+// The streamed-operand fragments go through a RING of 9 four-register slots in FIXED registers v[216:251], filled by
+// LDS reads issued from asm eight MFMAs ahead of their use (hipcc would not keep that many reads in flight, and it
+// treats the transposed-read builtin as aliasing the LDS-DMA in flight: an s_waitcnt vmcnt(0) per tile that drained the
+// prefetch).  An asm load's destination is valid only after the reader's own counted lgkmcnt wait (guide 5.7 item 1),
+// and a transposed fragment is filled by two loads, so the registers are named literally; every MFMA wrapper starts with
+// the counted wait.  LDS reads the compiler issues in between only make a counted wait stronger (LDS returns in order;
+// no scalar loads inside the loop).  Hazards the compiler cannot see inside an asm statement (guide 5.7 item 2):
+//   * a VALU-written operand needs two wait states before the MFMA reads it: NOP = true puts an s_nop 1 in front;
 //   * an MFMA result needs the matrix pipe's passes before any non-MFMA reader: fl_mfma_drain() after a chain.
-template <bool B_IN_ACC, bool FIRST>
+constexpr int kFlRing = 9;   // slots: one more than the fragments in flight
+constexpr int kFlAhead = 8;  // fragments in flight
+
+template <int SLOT, int OFF>
+__device__ __forceinline__ void fl_ring_read_s(bf16x8& f, int addr) {
+  static_assert(OFF >= 0 && OFF < 65536, "ds offset field");
+  if constexpr (SLOT == 0)
+    asm volatile("ds_read_b128 v[216:219], %1 offset:%c2" : "={v[216:219]}"(f) : "v"(addr), "i"(OFF));
+  else if constexpr (SLOT == 1)
+    asm volatile("ds_read_b128 v[220:223], %1 offset:%c2" : "={v[220:223]}"(f) : "v"(addr), "i"(OFF));
+  else if constexpr (SLOT == 2)
+    asm volatile("ds_read_b128 v[224:227], %1 offset:%c2" : "={v[224:227]}"(f) : "v"(addr), "i"(OFF));
+  else if constexpr (SLOT == 3)
+    asm volatile("ds_read_b128 v[228:231], %1 offset:%c2" : "={v[228:231]}"(f) : "v"(addr), "i"(OFF));
+  else if constexpr (SLOT == 4)
+    asm volatile("ds_read_b128 v[232:235], %1 offset:%c2" : "={v[232:235]}"(f) : "v"(addr), "i"(OFF));
+  else if constexpr (SLOT == 5)
+    asm volatile("ds_read_b128 v[236:239], %1 offset:%c2" : "={v[236:239]}"(f) : "v"(addr), "i"(OFF));
+  else if constexpr (SLOT == 6)
+    asm volatile("ds_read_b128 v[240:243], %1 offset:%c2" : "={v[240:243]}"(f) : "v"(addr), "i"(OFF));
+  else if constexpr (SLOT == 7)
+    asm volatile("ds_read_b128 v[244:247], %1 offset:%c2" : "={v[244:247]}"(f) : "v"(addr), "i"(OFF));
+  else if constexpr (SLOT == 8)
+    asm volatile("ds_read_b128 v[248:251], %1 offset:%c2" : "={v[248:251]}"(f) : "v"(addr), "i"(OFF));
+  else if constexpr (SLOT == 9)
+    asm volatile("ds_read_b128 v[252:255], %1 offset:%c2" : "={v[252:255]}"(f) : "v"(addr), "i"(OFF));
+}
+template <int SLOT, int OFF_LO, int OFF_HI>
+__device__ __forceinline__ void fl_ring_read_v(bf16x8& f, int addr_lo, int addr_hi) {
+  static_assert(OFF_LO >= 0 && OFF_HI < 65536, "ds offset field");
+  if constexpr (SLOT == 0)
+    asm volatile("ds_read_b64_tr_b16 v[216:217], %1 offset:%c3\n\tds_read_b64_tr_b16 v[218:219], %2 offset:%c4"
+                 : "={v[216:219]}"(f) : "v"(addr_lo), "v"(addr_hi), "i"(OFF_LO), "i"(OFF_HI));
+  else if constexpr (SLOT == 1)
+    asm volatile("ds_read_b64_tr_b16 v[220:221], %1 offset:%c3\n\tds_read_b64_tr_b16 v[222:223], %2 offset:%c4"
+                 : "={v[220:223]}"(f) : "v"(addr_lo), "v"(addr_hi), "i"(OFF_LO), "i"(OFF_HI));
+  else if constexpr (SLOT == 2)
+    asm volatile("ds_read_b64_tr_b16 v[224:225], %1 offset:%c3\n\tds_read_b64_tr_b16 v[226:227], %2 offset:%c4"
+                 : "={v[224:227]}"(f) : "v"(addr_lo), "v"(addr_hi), "i"(OFF_LO), "i"(OFF_HI));
+  else if constexpr (SLOT == 3)
+    asm volatile("ds_read_b64_tr_b16 v[228:229], %1 offset:%c3\n\tds_read_b64_tr_b16 v[230:231], %2 offset:%c4"
+                 : "={v[228:231]}"(f) : "v"(addr_lo), "v"(addr_hi), "i"(OFF_LO), "i"(OFF_HI));
+  else if constexpr (SLOT == 4)
+    asm volatile("ds_read_b64_tr_b16 v[232:233], %1 offset:%c3\n\tds_read_b64_tr_b16 v[234:235], %2 offset:%c4"
+                 : "={v[232:235]}"(f) : "v"(addr_lo), "v"(addr_hi), "i"(OFF_LO), "i"(OFF_HI));
+  else if constexpr (SLOT == 5)
+    asm volatile("ds_read_b64_tr_b16 v[236:237], %1 offset:%c3\n\tds_read_b64_tr_b16 v[238:239], %2 offset:%c4"
+                 : "={v[236:239]}"(f) : "v"(addr_lo), "v"(addr_hi), "i"(OFF_LO), "i"(OFF_HI));
+  else if constexpr (SLOT == 6)
+    asm volatile("ds_read_b64_tr_b16 v[240:241], %1 offset:%c3\n\tds_read_b64_tr_b16 v[242:243], %2 offset:%c4"
+                 : "={v[240:243]}"(f) : "v"(addr_lo), "v"(addr_hi), "i"(OFF_LO), "i"(OFF_HI));
+  else if constexpr (SLOT == 7)
+    asm volatile("ds_read_b64_tr_b16 v[244:245], %1 offset:%c3\n\tds_read_b64_tr_b16 v[246:247], %2 offset:%c4"
+                 : "={v[244:247]}"(f) : "v"(addr_lo), "v"(addr_hi), "i"(OFF_LO), "i"(OFF_HI));
+  else if constexpr (SLOT == 8)
+    asm volatile("ds_read_b64_tr_b16 v[248:249], %1 offset:%c3\n\tds_read_b64_tr_b16 v[250:251], %2 offset:%c4"
+                 : "={v[248:251]}"(f) : "v"(addr_lo), "v"(addr_hi), "i"(OFF_LO), "i"(OFF_HI));
+  else if constexpr (SLOT == 9)
+    asm volatile("ds_read_b64_tr_b16 v[252:253], %1 offset:%c3\n\tds_read_b64_tr_b16 v[254:255], %2 offset:%c4"
+                 : "={v[252:255]}"(f) : "v"(addr_lo), "v"(addr_hi), "i"(OFF_LO), "i"(OFF_HI));
+}
+// s (+)= A x B with A = ring fragment (streamed rows), B = stationary fragment (either register file).
+// NOTE on the accumulator: hipcc may copy an asm operand between two statements.  With a plain C++ "previous = next" at
+// the end of the pipelined loop it renamed the score accumulator in the MIDDLE of the chain to coalesce that copy
+// (v_mov of an MFMA result still in the matrix pipe: wrong scores, no fault).  The copy is therefore made by
+// fl_copy_scores (asm: nothing to coalesce, and it sits behind the whole output product), and
+// tools/diag/audit_flash_isa.py checks the compiled kernel for any compiler-issued instruction that touches the
+// destination of an MFMA still in flight.
+template <bool B_IN_ACC, bool FIRST, int WAIT>
 __device__ __forceinline__ void fl_mfma_s(f32x16& acc, const bf16x8& a, const bf16x8& b) {
   if constexpr (FIRST) {
-    if constexpr (B_IN_ACC) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=v"(acc) : "v"(a), "a"(b));
-    else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=v"(acc) : "v"(a), "v"(b));
+    if constexpr (B_IN_ACC)
+      asm volatile("s_waitcnt lgkmcnt(%c3)\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=v"(acc) : "v"(a), "a"(b), "i"(WAIT));
+    else
+      asm volatile("s_waitcnt lgkmcnt(%c3)\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=v"(acc) : "v"(a), "v"(b), "i"(WAIT));
   } else {
-    if constexpr (B_IN_ACC) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "a"(b));
-    else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+    if constexpr (B_IN_ACC)
+      asm volatile("s_waitcnt lgkmcnt(%c3)\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "a"(b), "i"(WAIT));
+    else
+      asm volatile("s_waitcnt lgkmcnt(%c3)\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b), "i"(WAIT));
   }
 }
-template <bool ACC_IN_ACC, bool FIRST>
+// o += P x V with P (A operand) in VGPRs, V = ring fragment
+template <bool ACC_IN_ACC, bool NOP, int WAIT>
 __device__ __forceinline__ void fl_mfma_o(f32x16& acc, const bf16x8& a, const bf16x8& b) {
-  if constexpr (FIRST) {
-    if constexpr (ACC_IN_ACC) asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
-    else asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+  if constexpr (NOP) {
+    if constexpr (ACC_IN_ACC)
+      asm volatile("s_waitcnt lgkmcnt(%c3)\n\ts_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b), "i"(WAIT));
+    else
+      asm volatile("s_waitcnt lgkmcnt(%c3)\n\ts_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b), "i"(WAIT));
   } else {
-    if constexpr (ACC_IN_ACC) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
-    else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+    if constexpr (ACC_IN_ACC)
+      asm volatile("s_waitcnt lgkmcnt(%c3)\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b), "i"(WAIT));
+    else
+      asm volatile("s_waitcnt lgkmcnt(%c3)\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b), "i"(WAIT));
   }
 }
-// Four transposed B fragments (two ds_read_b64_tr_b16 each) into FIXED registers, from asm: hipcc treats the tr-read
-// builtin as aliasing the LDS-DMA in flight and put an s_waitcnt vmcnt(0) in front of the first one of every tile, which
-// drained the three-tile prefetch.  An asm load's destination is only valid after the reader's own lgkmcnt wait (guide
-// 5.7 item 1), and one 4-register fragment is filled by two loads, so the registers are named literally: slot 0 =
-// v[224:239], slot 1 = v[240:255]; the fragments go straight into fl_mfma_o4, whose asm starts with the counted wait.
-template <int SLOT, int OFF_LO, int OFF_HI>
-__device__ __forceinline__ void fl_read_v4(bf16x8 (&f)[4], const int (&tb)[8]) {
-  static_assert(OFF_HI + 256 < 65536, "ds offset field");
-  if constexpr (SLOT == 0)
-    asm volatile("ds_read_b64_tr_b16 v[224:225], %4 offset:%c12\n\tds_read_b64_tr_b16 v[226:227], %5 offset:%c13\n\t"
-                 "ds_read_b64_tr_b16 v[228:229], %6 offset:%c12\n\tds_read_b64_tr_b16 v[230:231], %7 offset:%c13\n\t"
-                 "ds_read_b64_tr_b16 v[232:233], %8 offset:%c12\n\tds_read_b64_tr_b16 v[234:235], %9 offset:%c13\n\t"
-                 "ds_read_b64_tr_b16 v[236:237], %10 offset:%c12\n\tds_read_b64_tr_b16 v[238:239], %11 offset:%c13"
-                 : "={v[224:227]}"(f[0]), "={v[228:231]}"(f[1]), "={v[232:235]}"(f[2]), "={v[236:239]}"(f[3])
-                 : "v"(tb[0]), "v"(tb[1]), "v"(tb[2]), "v"(tb[3]), "v"(tb[4]), "v"(tb[5]), "v"(tb[6]), "v"(tb[7]),
-                   "i"(OFF_LO), "i"(OFF_HI));
-  else
-    asm volatile("ds_read_b64_tr_b16 v[240:241], %4 offset:%c12\n\tds_read_b64_tr_b16 v[242:243], %5 offset:%c13\n\t"
-                 "ds_read_b64_tr_b16 v[244:245], %6 offset:%c12\n\tds_read_b64_tr_b16 v[246:247], %7 offset:%c13\n\t"
-                 "ds_read_b64_tr_b16 v[248:249], %8 offset:%c12\n\tds_read_b64_tr_b16 v[250:251], %9 offset:%c13\n\t"
-                 "ds_read_b64_tr_b16 v[252:253], %10 offset:%c12\n\tds_read_b64_tr_b16 v[254:255], %11 offset:%c13"
-                 : "={v[240:243]}"(f[0]), "={v[244:247]}"(f[1]), "={v[248:251]}"(f[2]), "={v[252:255]}"(f[3])
-                 : "v"(tb[0]), "v"(tb[1]), "v"(tb[2]), "v"(tb[3]), "v"(tb[4]), "v"(tb[5]), "v"(tb[6]), "v"(tb[7]),
-                   "i"(OFF_LO), "i"(OFF_HI));
+// 20 wait states: covers the 8-pass and the 16-pass rule for "matrix result -> any other reader".
+// DRAIN = false: ordering point only (no instruction).
+template <bool DRAIN>
+__device__ __forceinline__ void fl_score_fence(f32x16& acc) {
+  if constexpr (DRAIN) asm volatile("s_nop 15\n\ts_nop 3" : "+v"(acc));
+  else asm volatile("" : "+v"(acc));
 }
-// wait until at most WAIT LDS reads are outstanding (the next chunk's eight), then four MFMAs o_e += P x V_e.
-// Compiler-issued LDS reads that slip in between only make the counted wait stronger (LDS returns in order).
-template <bool IN_ACC, bool FIRST, int WAIT>
-__device__ __forceinline__ void fl_mfma_o4(f32x16& o0, f32x16& o1, f32x16& o2, f32x16& o3, const bf16x8& p,
-                                           const bf16x8 (&f)[4]) {
-#define MI_FL_O4_BODY                                                                                       \
-  "s_waitcnt lgkmcnt(%c9)\n\ts_nop 1\n\t"                                                                  \
-  "v_mfma_f32_32x32x16_bf16 %0, %4, %5, %0\n\tv_mfma_f32_32x32x16_bf16 %1, %4, %6, %1\n\t"                 \
-  "v_mfma_f32_32x32x16_bf16 %2, %4, %7, %2\n\tv_mfma_f32_32x32x16_bf16 %3, %4, %8, %3"
-  (void)FIRST;
-  if constexpr (IN_ACC)
-    asm volatile(MI_FL_O4_BODY
-                 : "+a"(o0), "+a"(o1), "+a"(o2), "+a"(o3)
-                 : "v"(p), "v"(f[0]), "v"(f[1]), "v"(f[2]), "v"(f[3]), "i"(WAIT));
-  else
-    asm volatile(MI_FL_O4_BODY
-                 : "+v"(o0), "+v"(o1), "+v"(o2), "+v"(o3)
-                 : "v"(p), "v"(f[0]), "v"(f[1]), "v"(f[2]), "v"(f[3]), "i"(WAIT));
-#undef MI_FL_O4_BODY
-}
-
-// 20 wait states: covers the 8-pass and the 16-pass rule for "matrix result -> any other reader"
-__device__ __forceinline__ void fl_mfma_drain(f32x16& acc) { asm volatile("s_nop 15\n\ts_nop 3" : "+v"(acc)); }
 __device__ __forceinline__ void fl_mfma_drain_all() { asm volatile("s_nop 15\n\ts_nop 3" ::: "memory"); }
 // tile *= f (the rare rescale of the reference point).  For tiles in accumulator registers one asm statement per
 // register with ONE temporary: written as plain C++ the compiler reads all 192 accumulators into VGPRs first, and the
@@ -217,6 +279,15 @@ __device__ __forceinline__ void fl_scale_tile(f32x16& t, float f) {
     }
   }
 }
+__device__ __forceinline__ void fl_copy_scores(f32x16& dst, f32x16& src) {
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    float d;
+    const float e = src[r];
+    asm volatile("v_mov_b32 %0, %1" : "=v"(d) : "v"(e));
+    dst[r] = d;
+  }
+}
 template <bool IN_ACC>
 __device__ __forceinline__ void fl_pin(bf16x8& v) {
   if constexpr (IN_ACC) asm volatile("" : "+a"(v));
@@ -226,6 +297,16 @@ template <bool IN_ACC>
 __device__ __forceinline__ void fl_pin_o(f32x16& v) {
   if constexpr (IN_ACC) asm volatile("" : "+a"(v));
   else asm volatile("" : "+v"(v));
+}
+
+// Fragment stream of one loop iteration: F[0 .. NK) = row fragments of the NEXT tile (score product, one ds_read_b128
+// each), F[NK .. NK + 2 NT) = transposed fragments of the CURRENT tile (output product, two ds_read_b64_tr_b16 each).
+// lgkmcnt to wait for before the MFMA that consumes F[n] when reads up to F[min(n + AHEAD - 1, last)] have been issued.
+template <int NS, int NV>
+constexpr int fl_wait_count(int n) {
+  int c = 0;
+  for (int m = n + 1; m <= n + kFlAhead - 1 && m < NS + NV; ++m) c += m < NS ? 1 : 2;
+  return c;
 }
 
 template <int D, bool GRAD>
@@ -259,33 +340,10 @@ __global__ __launch_bounds__(256, 1) void bilinear_flash_kernel(FlashArgs args) 
   const int64_t m_wave = (int64_t)rb * kFlRows + wave * 32;  // first stationary row of this wave
   const bool wave_active = m_wave < P.m;                      // P.m % 32 == 0: a wave is all in or all out
   const int64_t gi = wave_active ? m_wave + r32 : r32;  // an idle wave re-reads rows 0..31; its outputs are dropped
-
   MI_FL_STAMP(0);
-  // ---- LDS-DMA pieces of this wave: piece q = PIECES * wave + i covers tile rows [q * RPP, (q + 1) * RPP)
-  const char* kv_base = reinterpret_cast<const char*>(P.kv + tile0 * kFlBN * D);
-  int src_off[C::PIECES];
-#pragma unroll
-  for (int i = 0; i < C::PIECES; ++i) {
-    const int q = C::PIECES * wave + i;
-    const int row = q * C::RPP + lane / C::CPR;
-    const int cp = lane % C::CPR;
-    src_off[i] = row * C::RB + 16 * (cp ^ fl_swz(row));
-  }
-  auto issue_tile = [&](int t) {
-    const int stage = t & (kFlStages - 1);
-    const char* src = kv_base + (int64_t)t * C::STAGE;
-#pragma unroll
-    for (int i = 0; i < C::PIECES; ++i)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + src_off[i]),
-                                       (__attribute__((address_space(3))) void*)(smem + stage * C::STAGE +
-                                                                                (C::PIECES * wave + i) * 1024),
-                                       16, 0, 0);
-  };
-  if (nt > 0) issue_tile(0);
-  if (nt > 1) issue_tile(1);
-  if (nt > 2) issue_tile(2);
 
-  // ---- stationary rows as B fragments: lane (n = r32, half) holds Q[gi][16 kk + 8 half .. + 7]
+  // ---- stationary rows as B fragments: lane (n = r32, half) holds Q[gi][16 kk + 8 half .. + 7].  Issued first: these
+  // plain loads have the longest latency of the prologue; the LDS-DMA issue below runs under it.
   bf16x8 qf[C::NK];
   {
     const bf16_t* qrow = P.q + gi * D + 8 * half;
@@ -293,6 +351,39 @@ __global__ __launch_bounds__(256, 1) void bilinear_flash_kernel(FlashArgs args) 
     for (int kk = 0; kk < C::NK; ++kk) qf[kk] = *reinterpret_cast<const bf16x8*>(qrow + 16 * kk);
   }
   const int64_t sid_i = P.sid_q[gi];
+  // which streamed tiles hold a pair with equal study ids for this wave's rows (bit t: tile tile0 + t); the diagonal is
+  // such a pair, so the positives only ever show up in flagged tiles
+  unsigned long long dupmask;
+  {
+    const unsigned char* df = P.dup + (wave_active ? m_wave / 32 : 0) * n_tiles_all + tile0;
+    const bool flag = lane < nt ? df[lane] != 0 : false;
+    dupmask = __ballot(flag);
+  }
+
+  // ---- LDS-DMA pieces of this wave: piece q = PIECES * wave + i covers tile rows [q * RPP, (q + 1) * RPP).  Lane l
+  // writes LDS chunk position cp = l % CPR of row q * RPP + l / CPR, which holds source chunk cp ^ swz(row); the swizzle
+  // splits into a per-lane part and a wave-uniform part U(q), so one VGPR (vlane) serves every piece:
+  //   source = [kv_base + t * STAGE + q * 1024] (scalar) + (vlane ^ 16 U(q)) (32-bit vector offset)
+  // Issued from asm in the scalar-base form: as a builtin hipcc kept a 64-bit address pair per piece (16 VGPRs), spilled
+  // some of them and waited vmcnt(0) on the scratch reloads inside the loop.
+  const char* kv_base = reinterpret_cast<const char*>(P.kv + tile0 * kFlBN * D);
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+  const int lr = lane / C::CPR;
+  const unsigned vlane = (unsigned)(lr * C::RB + 16 * ((lane % C::CPR) ^ (C::RPP > 1 ? (lr << 2) : 0)));
+  auto issue_piece = [&](int t, int i) __attribute__((always_inline)) {
+    const int q = C::PIECES * wave + i;
+    const int u = C::RPP == 1 ? fl_swz(q) : (C::RPP == 2 ? (8 * (q & 1)) | ((q >> 1) & 3) : (q & 3));
+    const int stage = t & (kFlStages - 1);
+    fl_dma16(vlane ^ (unsigned)(16 * u), kv_base + (int64_t)t * C::STAGE + q * 1024, lds0 + stage * C::STAGE + q * 1024);
+  };
+  auto issue_tile = [&](int t) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < C::PIECES; ++i) issue_piece(t, i);
+  };
+  if (nt > 0) issue_tile(0);
+  if (nt > 1) issue_tile(1);
+  if (nt > 2) issue_tile(2);
+
   // streamed study ids of this split -> LDS (plain loads: done before the pipeline's counted waits start)
   {
     int64_t* sl = reinterpret_cast<int64_t*>(smem + C::SID_OFF);
@@ -319,123 +410,156 @@ __global__ __launch_bounds__(256, 1) void bilinear_flash_kernel(FlashArgs args) 
   const int a1_lane = (4 * half + q4) * C::RB + 16 * ((cl ^ half) | (q4 << 2)) + 8 * (p4 & 1);
   const int d0_wave = (int)(m_wave + P.diag - tile0 * kFlBN);  // streamed offset of the wave's first positive
 
-  // the Q loads, the id copy and the first tiles must have landed
-  __syncthreads();  // hipcc drains vmcnt to 0 here (plain loads and LDS-DMA alike)
+  // the Q loads, the id copy and the first tiles must have landed (the asm-issued LDS-DMA is invisible to hipcc's own
+  // wait insertion: drain it by hand)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
   MI_FL_STAMP(1);
   // pin the register classes once: from here on only the asm MFMAs touch these values
-  fl_static_for<0, C::NK>([&](auto KK) { fl_pin<(decltype(KK)::value < C::QA)>(qf[decltype(KK)::value]); });
-  if constexpr (GRAD) fl_static_for<0, C::NT>([&](auto CT) { fl_pin_o<(decltype(CT)::value < C::OA)>(o[decltype(CT)::value]); });
+  fl_static_for<0, C::NK>([&](auto KK) __attribute__((always_inline)) { fl_pin<(decltype(KK)::value < C::QA)>(qf[decltype(KK)::value]); });
+  if constexpr (GRAD) fl_static_for<0, C::NT>([&](auto CT) __attribute__((always_inline)) { fl_pin_o<(decltype(CT)::value < C::OA)>(o[decltype(CT)::value]); });
 
-  for (int t = 0; t < nt; ++t) {
-    const bool stamp_tile = t == nt / 2;
-    if (stamp_tile) MI_FL_STAMP(2);
-    if (t == nt / 2 + 1) MI_FL_STAMP(10);
-    // ---- wait for tile t (own pieces), make every wave's pieces visible, refill the stage read one tile ago
-    if (t > 0) {
-      if (t + 2 < nt) fl_wait_vmcnt_barrier<2 * C::PIECES>();
-      else if (t + 1 < nt) fl_wait_vmcnt_barrier<C::PIECES>();
-      else fl_wait_vmcnt_barrier<0>();
-    }
-    if (stamp_tile) MI_FL_STAMP(3);
-    if (t + 3 < nt) issue_tile(t + 3);
-    const int stage_off = (t & (kFlStages - 1)) * C::STAGE;
-    if (stamp_tile) MI_FL_STAMP(4);
+  bf16x8 ring[kFlRing];
+  bf16x8 pf[2];
+  f32x16 s_prev, s_next;  // scores of the tile whose exponentials are due / of the tile being multiplied
 
-    // ---- X = K Q^T: streamed rows in the registers, stationary rows on the lanes.  Fragment reads run one chunk of
-    // four 16-deep steps ahead of the MFMAs; the scheduling fences bound the fragments in flight.
-    f32x16 s;
-    {
-      int abase[8];
+  // ---- softmax of the finished tile `s_prev` (tile index tp), cut into NSL slices that are placed one per MFMA gap of the
+  // next tile's score product.  Slice 0 holds the (rare) general mask; every other slice is a handful of VALU ops.
+  float tmax = MI_NEG_INF, off = 0.0f;
+  constexpr int NSL = 32;
+  auto sm_slice = [&](auto SI, int tp) __attribute__((always_inline)) {
+    constexpr int si = decltype(SI)::value;
+    if constexpr (si == 0) {
+      if (__builtin_amdgcn_readfirstlane((int)((dupmask >> tp) & 1ull))) {
+        // some pair of this tile shares a study id (always so on the diagonal): exact 64-bit compares, positives
+        const int64_t* sl = reinterpret_cast<const int64_t*>(smem + C::SID_OFF) + tp * kFlBN + 4 * half;
+        const int d0 = d0_wave - tp * kFlBN;  // streamed row (inside this tile) of stationary row 0's positive
+        if (__builtin_amdgcn_readfirstlane((int)(d0 > -32 && d0 < 32))) {
+          const int want = r32 + d0 - 4 * half;
 #pragma unroll
-      for (int v = 0; v < 8; ++v) abase[v] = (stage_off + a0_lane) ^ (32 * v);
-      constexpr int CH = 4, NCH = C::NK / CH;
-      bf16x8 kf[2][CH];
+          for (int r = 0; r < 16; ++r) pos += (want == (r & 3) + 8 * (r >> 2)) ? s_prev[r] : 0.0f;
+        }
 #pragma unroll
-      for (int e = 0; e < CH; ++e) kf[0][e] = *reinterpret_cast<const bf16x8*>(smem + abase[e & 7] + 256 * (e >> 3));
-      fl_static_for<0, NCH>([&](auto CI) {
-        constexpr int c = decltype(CI)::value;
-        if constexpr (c + 1 < NCH) {
-#pragma unroll
-          for (int e = 0; e < CH; ++e) {
-            const int kk = (c + 1) * CH + e;
-            kf[(c + 1) & 1][e] = *reinterpret_cast<const bf16x8*>(smem + abase[kk & 7] + 256 * (kk >> 3));
+        for (int r = 0; r < 16; ++r) {
+          const bool neg = sl[(r & 3) + 8 * (r >> 2)] != sid_i;
+          cnt += (unsigned)__popcll(__ballot(neg));
+          s_prev[r] = neg ? s_prev[r] : MI_NEG_INF;
+        }
+      } else {
+        cnt += 1024u;
+      }
+      tmax = fl_max3(s_prev[0], s_prev[1], MI_NEG_INF);
+    } else if constexpr (si >= 1 && si <= 7) {
+      tmax = fl_max3(tmax, s_prev[2 * si], s_prev[2 * si + 1]);
+    } else if constexpr (si == 8) {
+      tmax = wave_max_uniform(tmax);
+    } else if constexpr (si == 9) {
+      if (tmax > mref + kFlThr || (mref == MI_NEG_INF && tmax > MI_NEG_INF)) {
+        if (mref > MI_NEG_INF) {
+          const float f = __builtin_amdgcn_exp2f((mref - tmax) * kLog2e);
+          lsum *= f;
+          if constexpr (GRAD) {
+            fl_mfma_drain_all();
+            fl_static_for<0, C::NT>([&](auto CT) __attribute__((always_inline)) { fl_scale_tile<(decltype(CT)::value < C::OA)>(o[decltype(CT)::value], f); });
           }
         }
-        __builtin_amdgcn_sched_barrier(0);
-        fl_static_for<0, CH>([&](auto EI) {
-          constexpr int e = decltype(EI)::value, kk = c * CH + e;
-          fl_mfma_s<(kk < C::QA), kk == 0>(s, kf[c & 1][e], qf[kk]);
-        });
-        __builtin_amdgcn_sched_barrier(0);
-      });
-      fl_mfma_drain(s);
-    }
-    if (stamp_tile) MI_FL_STAMP(5);
-
-    // ---- mask, positives, reference point, exponentials
-    const int64_t* sl = reinterpret_cast<const int64_t*>(smem + C::SID_OFF) + t * kFlBN + 4 * half;
-    const int d0 = d0_wave - t * kFlBN;  // streamed row (inside this tile) of stationary row 0's positive
-    if (__builtin_amdgcn_readfirstlane((int)(d0 > -32 && d0 < 32))) {
-      const int want = r32 + d0 - 4 * half;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) pos += (want == (r & 3) + 8 * (r >> 2)) ? s[r] : 0.0f;
-    }
-    float tmax = MI_NEG_INF;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const bool neg = sl[(r & 3) + 8 * (r >> 2)] != sid_i;
-      cnt += (unsigned)__popcll(__ballot(neg));
-      s[r] = neg ? s[r] : MI_NEG_INF;
-      tmax = fmaxf(tmax, s[r]);
-    }
-    tmax = wave_max_uniform(tmax);
-    if (tmax > mref + kFlThr || (mref == MI_NEG_INF && tmax > MI_NEG_INF)) {
-      if (mref > MI_NEG_INF) {
-        const float f = __builtin_amdgcn_exp2f((mref - tmax) * kLog2e);
-        lsum *= f;
-        if constexpr (GRAD) {
-          fl_mfma_drain_all();
-          fl_static_for<0, C::NT>([&](auto CT) { fl_scale_tile<(decltype(CT)::value < C::OA)>(o[decltype(CT)::value], f); });
-        }
+        mref = tmax;
       }
-      mref = tmax;
-    }
-    const float off = mref > MI_NEG_INF ? -mref * kLog2e : 0.0f;
+      off = mref > MI_NEG_INF ? -mref * kLog2e : 0.0f;
+    } else if constexpr (si >= 10 && si <= 25) {
+      constexpr int r = si - 10;
+      s_prev[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s_prev[r], kLog2e, off));  // masked entries: exp2(-inf) = 0
+      lsum += s_prev[r];
+    } else if constexpr (si == 26 || si == 27) {
+      if constexpr (GRAD) {
+        constexpr int ks = si - 26;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      s[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[r], kLog2e, off));  // masked entries: exp2(-inf) = 0
-      lsum += s[r];
+        for (int e = 0; e < 8; ++e) pf[ks][e] = (bf16_t)s_prev[8 * ks + e];
+      }
     }
+  };
 
-    if (stamp_tile) MI_FL_STAMP(6);
-    if constexpr (GRAD) {
-      // ---- O += P (A operand straight from the accumulator layout) x V (transposed reads of the same tile)
-      bf16x8 pf[2];
+  // ---- one loop iteration: [score product of tile tn = tp + 1 (HAS_S)] with the softmax slices of tile tp in its MFMA
+  // gaps, then [output product of tile tp (HAS_V)] with the LDS-DMA pieces of tile tp + 3 in its gaps
+  auto iteration = [&](auto HAS_S_, auto HAS_V_, int tp) __attribute__((always_inline)) {
+    constexpr bool HAS_S = decltype(HAS_S_)::value, HAS_V = decltype(HAS_V_)::value && GRAD;
+    constexpr bool DO_SM = decltype(HAS_V_)::value;  // a finished tile is waiting for its exponentials
+    constexpr int NS = HAS_S ? C::NK : 0, NV = HAS_V ? 2 * C::NT : 0, NF = NS + NV;
+    const int so = ((tp + 1) & (kFlStages - 1)) * C::STAGE + a0_lane;  // row reads of tile tp + 1
+    const int vo = (tp & (kFlStages - 1)) * C::STAGE + a1_lane;       // transposed reads of tile tp
+    int abase[8], tbase[8];
+    if constexpr (HAS_S) {
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-        for (int e = 0; e < 8; ++e) pf[ks][e] = (bf16_t)s[8 * ks + e];
-      int tbase[8];  // index 2 * (ct & 3) + tt
-#pragma unroll
-      for (int v = 0; v < 8; ++v) tbase[v] = (stage_off + a1_lane) ^ (16 * ((4 * (v >> 1)) ^ (2 * (v & 1))));
-      // step u = ks * NT + ct in chunks of four (one chunk = one ks, four consecutive column tiles): the transposed
-      // reads of chunk c + 1 are issued, then the MFMAs of chunk c run behind a counted lgkmcnt.
-      constexpr int NCH = 2 * C::NT / 4, CPK = C::NT / 4;  // chunks; chunks per ks
-      bf16x8 vf[2][4];
-      fl_read_v4<0, 0, 8 * C::RB>(vf[0], tbase);
-      fl_static_for<0, NCH>([&](auto CI) {
-        constexpr int c = decltype(CI)::value, ks = c / CPK, ct0 = 4 * (c % CPK);
-        if constexpr (c + 1 < NCH) {
-          constexpr int c1 = c + 1, ks1 = c1 / CPK, hi1 = c1 % CPK;
-          fl_read_v4<(c1 & 1), 256 * hi1 + 16 * ks1 * C::RB, 256 * hi1 + (16 * ks1 + 8) * C::RB>(vf[c1 & 1], tbase);
-        }
-        fl_mfma_o4<(ct0 < C::OA), (c % CPK == 0), (c + 1 < NCH ? 8 : 0)>(o[ct0], o[ct0 + 1], o[ct0 + 2], o[ct0 + 3], pf[ks],
-                                                                       vf[c & 1]);
-      });
+      for (int v = 0; v < 8; ++v) abase[v] = so ^ (32 * v);
     }
-    if (stamp_tile) MI_FL_STAMP(7);
+    if constexpr (HAS_V) {
+#pragma unroll
+      for (int v = 0; v < 8; ++v) tbase[v] = vo ^ (16 * ((4 * (v >> 1)) ^ (2 * (v & 1))));
+    }
+    auto issue_read = [&](auto NI) __attribute__((always_inline)) {
+      constexpr int n = decltype(NI)::value;
+      if constexpr (n < NS) {
+        fl_ring_read_s<n % kFlRing, 256 * (n >> 3)>(ring[n % kFlRing], abase[n & 7]);
+      } else if constexpr (n < NF) {
+        constexpr int u = n - NS, ks = u / C::NT, ct = u % C::NT;
+        fl_ring_read_v<n % kFlRing, 256 * (ct >> 2) + 16 * ks * C::RB, 256 * (ct >> 2) + (16 * ks + 8) * C::RB>(
+            ring[n % kFlRing], tbase[2 * (ct & 3)], tbase[2 * (ct & 3) + 1]);
+      }
+    };
+    fl_static_for<0, kFlAhead>([&](auto NI) __attribute__((always_inline)) { issue_read(NI); });
+    // score product + softmax slices
+    fl_static_for<0, NS>([&](auto NI) __attribute__((always_inline)) {
+      constexpr int n = decltype(NI)::value;
+      fl_mfma_s<(n < C::QA), n == 0, fl_wait_count<NS, NV>(n)>(s_next, ring[n % kFlRing], qf[n]);
+      issue_read(std::integral_constant<int, n + kFlAhead>{});
+      if constexpr (DO_SM) {
+        constexpr int per = (NSL + (NS > 0 ? NS : 1) - 1) / (NS > 0 ? NS : 1);  // slices per gap (1 at D = 512, 2 at 256, 4 at 128)
+        fl_static_for<n * per, (n * per + per < NSL ? n * per + per : NSL)>([&](auto SI) __attribute__((always_inline)) { sm_slice(SI, tp); });
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    });
+    if constexpr (DO_SM && !HAS_S) fl_static_for<0, NSL>([&](auto SI) __attribute__((always_inline)) { sm_slice(SI, tp); });
+    if constexpr (HAS_S && !HAS_V) fl_score_fence<true>(s_next);  // with an output product behind it the chain is long done
+    // output product + LDS-DMA issue for tile tp + 3
+    if constexpr (HAS_V) {
+      constexpr int EVERY = NV / C::PIECES;
+      const bool more = tp + 3 < nt;
+      fl_static_for<0, NV>([&](auto UI) __attribute__((always_inline)) {
+        constexpr int u = decltype(UI)::value, n = NS + u, ks = u / C::NT, ct = u % C::NT;
+        fl_mfma_o<(ct < C::OA), (u % C::NT == 0), fl_wait_count<NS, NV>(n)>(o[ct], pf[ks], ring[n % kFlRing]);
+        issue_read(std::integral_constant<int, n + kFlAhead>{});
+        if constexpr (u % EVERY == EVERY - 1) {
+          if (more) issue_piece(tp + 3, u / EVERY);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      });
+      if constexpr (HAS_S) fl_score_fence<false>(s_next);  // readers of s_next stay behind the output product
+    } else if constexpr (DO_SM) {
+      if (tp + 3 < nt) issue_tile(tp + 3);
+    }
+  };
+  using T_ = std::true_type;
+  using F_ = std::false_type;
+
+  if (nt > 0) {
+    // tile 0's scores, nothing to overlap with yet (tp = -1: the "next" tile is tile 0)
+    iteration(T_{}, F_{}, -1);
+    fl_copy_scores(s_prev, s_next);
+    for (int t = 0; t + 1 < nt; ++t) {
+      if (t == nt / 2) MI_FL_STAMP(2);
+      // tile t + 1 must have landed (own pieces, then everybody's); every wave is done with tile t - 1, whose stage the
+      // pieces issued in this iteration refill.  Outstanding here: tiles t + 1 and t + 2.
+      if (t + 2 < nt) fl_wait_vmcnt_barrier<C::PIECES>();
+      else fl_wait_vmcnt_barrier<0>();
+      if (t == nt / 2) MI_FL_STAMP(3);
+      iteration(T_{}, T_{}, t);
+      fl_copy_scores(s_prev, s_next);
+      if (t == nt / 2) MI_FL_STAMP(4);
+    }
+    MI_FL_STAMP(8);
+    iteration(F_{}, T_{}, nt - 1);
   }
-  MI_FL_STAMP(8);
+  MI_FL_STAMP(9);
 
   // ---- records and partial sums
   lsum = wave_sum(lsum);
@@ -458,7 +582,56 @@ __global__ __launch_bounds__(256, 1) void bilinear_flash_kernel(FlashArgs args) 
         }
     }
   }
-  MI_FL_STAMP(9);
+  MI_FL_STAMP(10);
+}
+
+// ------------------------------------------------------------------------------------------------ equal-id tile flags
+// flag[a][b] = 1 iff some image row i of block a (32 rows) and some text row j of block b share a study id (the diagonal
+// pairs a sample with itself, so diagonal blocks are always flagged); flag_t is the transposed copy (problem 1 walks the
+// image blocks for a fixed text block).  Exact 64-bit compares, done once per step for all B^2 / 1024 tiles: the fused
+// kernel then takes its general mask path only in flagged tiles (none but the diagonal for a batch of distinct studies).
+static __global__ __launch_bounds__(256) void flash_dup_flags_kernel(const int64_t* __restrict__ sid_rows,
+                                                                     const int64_t* __restrict__ sid_cols, int na, int nb,
+                                                                     unsigned char* __restrict__ flag,
+                                                                     unsigned char* __restrict__ flag_t) {
+  __shared__ int64_t rows[32];
+  const int a = blockIdx.x, tid = threadIdx.x;
+  if (tid < 32) rows[tid] = sid_rows[a * 32 + tid];
+  __syncthreads();
+  const int q = tid & 3;             // rows 8 q .. 8 q + 7
+  int64_t mine[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) mine[e] = rows[8 * q + e];
+  for (int b = blockIdx.y * 64 + (tid >> 2); b < nb; b += gridDim.y * 64) {
+    const int64_t* c = sid_cols + (int64_t)b * 32;
+    bool any = false;
+    for (int j = 0; j < 32; ++j) {
+      const int64_t v = c[j];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) any |= v == mine[e];
+    }
+    int f = any ? 1 : 0;
+    f |= __shfl_xor(f, 1);
+    f |= __shfl_xor(f, 2);
+    if (q == 0) {
+      flag[(int64_t)a * nb + b] = (unsigned char)f;
+      flag_t[(int64_t)b * na + a] = (unsigned char)f;
+    }
+  }
+}
+
+static inline int launch_flash_dup_flags(const int64_t* sid_rows, const int64_t* sid_cols, int64_t br, int64_t b,
+                                         unsigned char* flag, unsigned char* flag_t, hipStream_t st) {
+  const int na = (int)(br / 32), nb = (int)(b / 32);
+  int gy = (nb + 63) / 64;
+  if (gy > 8) gy = 8;
+  {
+    ProfScope prof_("bilinear equal-id tile flags", st);
+    hipLaunchKernelGGL(flash_dup_flags_kernel, dim3((unsigned)na, (unsigned)gy), dim3(256), 0, st, sid_rows, sid_cols, na, nb,
+                       flag, flag_t);
+  }
+  MI_LAUNCH_CHECK("flash_dup_flags_kernel");
+  return MI_OK;
 }
 
 // ------------------------------------------------------------------------------------------------ slab reduce

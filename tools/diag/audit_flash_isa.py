@@ -1,0 +1,121 @@
+#!/usr/bin/env python3
+"""Static audit of the compiled fused bilinear kernel (csrc/mi_bilinear_flash.h).
+
+The kernel issues its MFMAs from inline asm, so hipcc's hazard recognizer does not see them: nothing stops the compiler
+from placing one of ITS instructions (a register copy, a spill, a scheduled VALU op) on the destination registers of a
+matrix instruction that is still in the matrix pipe -- which reads stale data or corrupts the accumulator without any
+fault.  (It happened once: see the note at fl_mfma_s.)  This script compiles mi_bilinear.hip to assembly and checks, for
+every bilinear_flash_kernel instantiation:
+
+  * no instruction other than an MFMA accumulating into the same registers touches the destination of an MFMA issued
+    fewer than WAIT_STATES wait states earlier (one per instruction, N + 1 per `s_nop N`);
+  * no scratch (spill) instruction inside a loop;
+  * no `s_waitcnt vmcnt(0)` inside a loop (it would drain the LDS-DMA prefetch).
+
+Exit status 0 = clean.  Used by tests/test_flash_isa_audit.py (CPU suite) and by hand after kernel edits.
+"""
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..")
+CSRC = os.path.join(ROOT, "mutual-information-multimodal_amd", "csrc")
+WAIT_STATES = 18  # 16-pass rule; v_mfma_f32_32x32x16_bf16 is an 8-pass instruction (11 needed)
+
+REG = re.compile(r"\b([va])\[(\d+):(\d+)\]|\b([va])(\d+)\b")
+
+
+def regs_of(text):
+    out = set()
+    for m in REG.finditer(text):
+        if m.group(1):
+            out.update((m.group(1), k) for k in range(int(m.group(2)), int(m.group(3)) + 1))
+        else:
+            out.add((m.group(4), int(m.group(5))))
+    return out
+
+
+def compile_asm():
+    out = os.path.join(tempfile.mkdtemp(prefix="mi_audit_"), "mi_bilinear.s")
+    cmd = ["hipcc", "-O3", "-std=c++17", "-fPIC", "-fno-slp-vectorize", "--offload-arch=gfx950", "-S",
+           "--cuda-device-only", "-o", out, os.path.join(CSRC, "mi_bilinear.hip")]
+    subprocess.run(cmd, check=True, stderr=subprocess.DEVNULL)
+    with open(out) as f:
+        return f.read()
+
+
+def kernels(asm):
+    for m in re.finditer(r"^(_ZN2mi21bilinear_flash_kernel\w+):[^\n]*\n", asm, re.M):
+        end = asm.index(".Lfunc_end", m.end())
+        yield m.group(1), asm[m.end():end]
+
+
+def audit(name, body):
+    problems = []
+    inflight = []  # [set of regs, wait states since issue]
+    in_loop = False
+    seen_mfma = False  # the prologue's id-copy loop legitimately waits for its plain loads
+    lines = body.split("\n")
+    for ln, raw in enumerate(lines, 1):
+        line = raw.split(";")[0].strip() if not raw.strip().startswith(";") else ""
+        if "Loop Header" in raw or "in Loop:" in raw:
+            in_loop = True
+        elif raw.startswith(".LBB") and "Loop" not in raw:
+            in_loop = False
+        if not line or line.endswith(":") or line.startswith("."):
+            continue
+        op = line.split()[0]
+        operands = line[len(op):]
+        states = 1
+        if op == "s_nop":
+            states = int(operands.strip()) + 1
+        if op.startswith("v_mfma"):
+            parts = [p.strip() for p in operands.split(",")]
+            dst, srcc = regs_of(parts[0]), regs_of(parts[3]) if len(parts) > 3 else set()
+            others = regs_of(parts[1]) | regs_of(parts[2])
+            for regs, age in inflight:
+                if age < WAIT_STATES and (regs & others):
+                    problems.append(f"{name}:{ln}: MFMA reads an in-flight MFMA result as A/B: {line}")
+                if age < WAIT_STATES and (regs & (dst | srcc)) and regs != dst:
+                    problems.append(f"{name}:{ln}: MFMA overlaps an in-flight MFMA destination partially: {line}")
+            inflight.append([dst, 0])
+            seen_mfma = True
+        else:
+            touched = regs_of(operands)
+            for regs, age in inflight:
+                if age < WAIT_STATES and (regs & touched):
+                    problems.append(f"{name}:{ln}: `{line}` touches the destination of an MFMA issued {age} wait states earlier")
+            if in_loop and op.startswith("scratch_"):
+                problems.append(f"{name}:{ln}: scratch access inside a loop: {line}")
+            if in_loop and seen_mfma and op == "s_waitcnt" and "vmcnt(0)" in operands:
+                nxt = next((x.strip() for x in lines[ln:] if x.strip() and not x.strip().startswith(";")), "")
+                if not nxt.startswith("s_barrier"):  # the hand-placed "last tile" wait is followed by its barrier
+                    problems.append(f"{name}:{ln}: s_waitcnt vmcnt(0) inside a loop (drains the LDS-DMA prefetch)")
+        for it in inflight:
+            it[1] += states
+        inflight = [it for it in inflight if it[1] < WAIT_STATES]
+    return problems
+
+
+def main():
+    asm = compile_asm()
+    found = False
+    bad = []
+    for name, body in kernels(asm):
+        found = True
+        p = audit(name, body)
+        n_mfma = len(re.findall(r"^\s*v_mfma", body, re.M))
+        print(f"{name}: {n_mfma} MFMAs, {len(p)} problem(s)")
+        bad += p
+    if not found:
+        print("no bilinear_flash_kernel instantiation found in the assembly")
+        return 2
+    for b in bad[:40]:
+        print("  " + b)
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -42,14 +42,11 @@ def seg(name, a, c):
     d_ = s[:, c] - s[:, a]
     print(f"{name:34s} median {np.median(d_):9.0f}  p10 {np.percentile(d_,10):9.0f}  p90 {np.percentile(d_,90):9.0f}")
 seg("prologue (entry -> first barrier)", 0, 1)
-seg("whole loop", 1, 8)
-seg("epilogue (records + slab stores)", 8, 9)
-seg("whole workgroup", 0, 9)
-print("--- one tile (t = nt/2)")
+seg("tile 0 scores + pipelined loop", 1, 8)
+seg("last tile (softmax + output product)", 8, 9)
+seg("epilogue (records + slab stores)", 9, 10)
+seg("whole workgroup", 0, 10)
+print("--- one pipelined iteration (t = nt/2)")
 seg("wait + barrier", 2, 3)
-seg("LDS-DMA issue of tile t+3", 3, 4)
-seg("S phase (32 MFMAs + drain)", 4, 5)
-seg("mask / max / exp", 5, 6)
-seg("PV phase (32 MFMAs)", 6, 7)
-seg("tile period (top -> next top)", 2, 10)
-print(f"start skew: median {np.median(s[:,0]-t0):.0f} max {np.max(s[:,0]-t0):.0f}; kernel span {s[:,9].max()-t0} ticks")
+seg("scores(t+1) | softmax(t) | output(t)", 3, 4)
+print(f"kernel span {s[:,10].max()-s[:,0].min()} ticks")
