@@ -40,6 +40,7 @@ struct BilinearPlan {
   float* fl_slab[2];
   Partial* fl_rec[2];
   unsigned char* fl_dup[2];  // equal-id flags per 32 x 32 block: [br / 32][b / 32] and its transpose
+  bf16_t *tfb, *yfb;         // fragment-major copies of T and Y: the stationary operands of the fused kernel
   size_t bytes;
 };
 
@@ -68,6 +69,8 @@ static BilinearPlan plan_bilinear(Workspace& ws, int64_t br, int64_t b, int64_t 
     p.fl_slab[q] = p.fl.ok ? ws.take<float>(p.fl.slab_floats[q]) : nullptr;
     p.fl_dup[q] = p.fl.ok ? ws.take<unsigned char>((br / 32) * (b / 32)) : nullptr;
   }
+  p.tfb = p.fl.ok ? ws.take<bf16_t>(br * dy) : nullptr;
+  p.yfb = p.fl.ok ? ws.take<bf16_t>(b * dy) : nullptr;
   // backward
   p.dt = ws.take<float>(br * dy);
   if (precision == MI_PREC_BF16) p.g = ws.take<bf16_t>(br * b);
@@ -113,17 +116,21 @@ static GemmBf16Args one_problem(const bf16_t* a, int64_t lda, const bf16_t* b, i
 }
 
 // ------------------------------------------------------------------------------------------------ fast path
-static int fast_prep_and_t(const float* x, const float* y, const float* w, int64_t br, int64_t b, int64_t dx, int64_t dy,
-                           const BilinearPlan& p, hipStream_t st) {
+static int fast_prep_and_t(const float* x, const float* y, const float* w, const int64_t* sid_rows,
+                           const int64_t* sid_cols, int64_t br, int64_t b, int64_t dx, int64_t dy, const BilinearPlan& p,
+                           hipStream_t st) {
+  // With the fused B x B kernel nobody reads Y^T or T^T any more; instead T and Y get a fragment-major copy (the
+  // kernel's stationary operand, loaded straight into MFMA B fragments) and the equal-id tile flags ride along.
   CvtJobs jobs{};
-  jobs.j[0] = CvtJob{x, br, dx, p.xb, p.xtb};
-  jobs.j[1] = CvtJob{y, b, dy, p.yb, p.ytb};
-  jobs.j[2] = CvtJob{w, dx, dy, p.wb, p.wtb};
+  jobs.j[0] = CvtJob{x, br, dx, p.xb, p.xtb, 0, 0, nullptr};
+  jobs.j[1] = CvtJob{y, b, dy, p.yb, p.fl.ok ? nullptr : p.ytb, 0, 0, p.fl.ok ? p.yfb : nullptr};
+  jobs.j[2] = CvtJob{w, dx, dy, p.wb, p.wtb, 0, 0, nullptr};
+  if (p.fl.ok) jobs.dup = DupFlagJob{sid_rows, sid_cols, (int)(br / 32), (int)(b / 32), p.fl_dup[0], p.fl_dup[1]};
   int rc = launch_cvt_transpose3(jobs, st, "bilinear prep X Y W");
   if (rc) return rc;
   // T[i, c] = sum_a X[i, a] W[a, c]: A = Xb [br][dx], B = W^T [dy][dx]
   EpiStoreMulti e{};
-  e.out[0] = EpiOut{nullptr, 0, 0, p.tb, dy, p.ttb, br};
+  e.out[0] = EpiOut{nullptr, 0, 0, p.tb, dy, p.fl.ok ? nullptr : p.ttb, br, p.fl.ok ? p.tfb : nullptr};
   return launch_gemm_bf16(one_problem(p.xb, dx, p.wtb, dx, br, dy, dx), 1, e, st, "bilinear T = X W");
 }
 
@@ -136,11 +143,9 @@ static int bilinear_bwd_small(int64_t br, int64_t dx, int64_t dy, float* grad_x,
 static int flash_stage(const int64_t* sid_rows, const int64_t* sid_cols, int64_t br, int64_t b, int64_t row_offset,
                        int64_t dy, bool grad, const BilinearPlan& p, hipStream_t st) {
   FlashArgs a{};
-  int rc = launch_flash_dup_flags(sid_rows, sid_cols, br, b, p.fl_dup[0], p.fl_dup[1], st);
-  if (rc) return rc;
-  a.p[0] = FlashProblem{p.tb, p.yb, sid_rows, sid_cols, br, b, row_offset, p.fl.n_rb[0], p.fl.n_split[0],
+  a.p[0] = FlashProblem{p.tfb, p.yb, sid_rows, sid_cols, br, b, row_offset, p.fl.n_rb[0], p.fl.n_split[0],
                         p.fl.tiles_per_split[0], p.fl_dup[0], p.fl_slab[0], p.fl_rec[0]};
-  a.p[1] = FlashProblem{p.yb, p.tb, sid_cols, sid_rows, b, br, -row_offset, p.fl.n_rb[1], p.fl.n_split[1],
+  a.p[1] = FlashProblem{p.yfb, p.tb, sid_cols, sid_rows, b, br, -row_offset, p.fl.n_rb[1], p.fl.n_split[1],
                         p.fl.tiles_per_split[1], p.fl_dup[1], p.fl_slab[1], p.fl_rec[1]};
   a.n_problems = grad ? 2 : 1;
   return launch_flash(a, dy, grad, st, grad ? "bilinear fused S | P Y | P^T T" : "bilinear fused S + LSE");
@@ -150,7 +155,7 @@ static int bilinear_fwd_fast(const float* x, const float* y, const float* w, con
                              const int64_t* sid_cols, int64_t br, int64_t b, int64_t row_offset, int64_t dx, int64_t dy,
                              int estimator, int need_grad, float* loss_out, mi_stats* stats, float* partials_out,
                              float* scores_out, const BilinearPlan& p, hipStream_t st) {
-  int rc = fast_prep_and_t(x, y, w, br, b, dx, dy, p, st);
+  int rc = fast_prep_and_t(x, y, w, sid_rows, sid_cols, br, b, dx, dy, p, st);
   if (rc) return rc;
   if (p.fl.ok) {
     rc = flash_stage(sid_rows, sid_cols, br, b, row_offset, dy, need_grad != 0, p, st);
@@ -380,7 +385,7 @@ int mi_bilinear_bwd(const float* x, const float* y, const float* w, const int64_
   hipStream_t st = (hipStream_t)stream;
   if (fast_ok(b_rows, b, d_img, d_txt, precision, w != nullptr)) {
     if (!workspace_from_forward) {  // rebuild the bf16 operand copies, T and the fused sums
-      rc = fast_prep_and_t(x, y, w, b_rows, b, d_img, d_txt, p, st);
+      rc = fast_prep_and_t(x, y, w, sid_rows, sid_cols, b_rows, b, d_img, d_txt, p, st);
       if (rc) return rc;
       if (p.fl.ok) {
         rc = flash_stage(sid_rows, sid_cols, b_rows, b, row_offset, d_txt, true, p, st);

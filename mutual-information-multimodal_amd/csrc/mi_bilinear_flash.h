@@ -55,7 +55,7 @@ constexpr float kFlThr = 24.0f;  // raise the reference point when a tile maximu
 constexpr int kFlMaxTilesPerSplit = 64;  // streamed study ids of a split sit in LDS: 64 tiles x 32 x 8 bytes = 16 KB
 
 struct FlashProblem {
-  const bf16_t* q;        // stationary operand [m][D]
+  const bf16_t* q;        // stationary operand [m][D] in FRAGMENT-MAJOR order (EpiOut::bf_frag, mi_gemm_bf16.h)
   const bf16_t* kv;       // streamed operand   [n][D]
   const int64_t* sid_q;   // [m]
   const int64_t* sid_kv;  // [n]
@@ -72,6 +72,8 @@ struct FlashArgs {
   FlashProblem p[2];
   int n_problems;
   int n_combo;  // (problem, split) pairs, padded to a multiple of 8
+  int diag;     // diagnostic (MI_STAMPS) builds only, timing experiments with WRONG results: bit 0 no LDS-DMA in the loop,
+                // bit 1 no softmax slices, bit 2 no workgroup barrier in the loop (MI_FLASH_DIAG in the environment)
 };
 
 template <int D>
@@ -113,7 +115,13 @@ __device__ __forceinline__ float wave_max_uniform(float v) {
 // M0 carries the LDS address and is compiler-reserved: saved and restored inside the statement (guide 5.7).
 __device__ __forceinline__ void fl_dma16(unsigned voff, const void* sbase, unsigned lds_addr) {
   unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+  // the scalar operands are wave-uniform by construction; readfirstlane makes that provable to hipcc (guide T20).  A
+  // VMEM instruction needs 4 wait states after a VALU (v_readfirstlane) write of its scalar base: s_mov, s_mov, s_nop 1.
+  const uintptr_t b = (uintptr_t)sbase;
+  const unsigned blo = __builtin_amdgcn_readfirstlane((unsigned)b), bhi = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32));
+  sbase = (const void*)(((uintptr_t)bhi << 32) | blo);
+  lds_addr = __builtin_amdgcn_readfirstlane(lds_addr);
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 1\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
                : "=&s"(keep)
                : "v"(voff), "s"(sbase), "s"(lds_addr)
                : "memory");
@@ -314,20 +322,43 @@ __global__ __launch_bounds__(256, 1) void bilinear_flash_kernel(FlashArgs args) 
   using C = FlashCfg<D>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
-  // ---- which (problem, split, row block)
+  // ---- which (problem, split, row block).  Every field of BOTH problem records is read before anything depends on
+  // one of them: the kernel-argument segment is cold when a workgroup starts, and the natural "decode, pick a problem,
+  // then read its fields" order cost four to five DEPENDENT scalar-load round trips (~11,000 cycles per workgroup, in-
+  // kernel stamps).  Read up front, the loads overlap; the problem is then picked with scalar selects.
+  const FlashProblem A = args.p[0], Bp = args.p[1];
+  const int n_combo = args.n_combo, n_problems = args.n_problems;
+  asm volatile("" ::"s"(A.q), "s"(A.kv), "s"(A.sid_q), "s"(A.sid_kv), "s"(A.m), "s"(A.n), "s"(A.diag), "s"(A.n_rb),
+               "s"(A.n_split), "s"(A.tiles_per_split), "s"(A.dup), "s"(A.slab), "s"(A.rec));
+  asm volatile("" ::"s"(Bp.q), "s"(Bp.kv), "s"(Bp.sid_q), "s"(Bp.sid_kv), "s"(Bp.m), "s"(Bp.n), "s"(Bp.diag), "s"(Bp.n_rb),
+               "s"(Bp.n_split), "s"(Bp.tiles_per_split), "s"(Bp.dup), "s"(Bp.slab), "s"(Bp.rec), "s"(n_combo),
+               "s"(n_problems));
   const int L = (int)blockIdx.x;
-  const int combo = L % args.n_combo, rb = L / args.n_combo;
+  const int combo = L % n_combo, rb = L / n_combo;
   int prob, split;
-  if (combo < args.p[0].n_split) {
+  if (combo < A.n_split) {
     prob = 0;
     split = combo;
-  } else if (args.n_problems == 2 && combo < args.p[0].n_split + args.p[1].n_split) {
+  } else if (n_problems == 2 && combo < A.n_split + Bp.n_split) {
     prob = 1;
-    split = combo - args.p[0].n_split;
+    split = combo - A.n_split;
   } else {
     return;
   }
-  const FlashProblem& P = args.p[prob];
+  FlashProblem P;
+  P.q = prob ? Bp.q : A.q;
+  P.kv = prob ? Bp.kv : A.kv;
+  P.sid_q = prob ? Bp.sid_q : A.sid_q;
+  P.sid_kv = prob ? Bp.sid_kv : A.sid_kv;
+  P.m = prob ? Bp.m : A.m;
+  P.n = prob ? Bp.n : A.n;
+  P.diag = prob ? Bp.diag : A.diag;
+  P.n_rb = prob ? Bp.n_rb : A.n_rb;
+  P.n_split = prob ? Bp.n_split : A.n_split;
+  P.tiles_per_split = prob ? Bp.tiles_per_split : A.tiles_per_split;
+  P.dup = prob ? Bp.dup : A.dup;
+  P.slab = prob ? Bp.slab : A.slab;
+  P.rec = prob ? Bp.rec : A.rec;
   if (rb >= P.n_rb) return;
   const int64_t n_tiles_all = P.n / kFlBN;
   const int64_t tile0 = (int64_t)split * P.tiles_per_split;
@@ -346,11 +377,13 @@ __global__ __launch_bounds__(256, 1) void bilinear_flash_kernel(FlashArgs args) 
   // plain loads have the longest latency of the prologue; the LDS-DMA issue below runs under it.
   bf16x8 qf[C::NK];
   {
-    const bf16_t* qrow = P.q + gi * D + 8 * half;
+    // fragment-major source: the (32-row block, kk) fragment block is 1 KB in lane order -> fully coalesced loads
+    const bf16_t* qblk = P.q + ((gi >> 5) * C::NK * 64 + lane) * 8;
 #pragma unroll
-    for (int kk = 0; kk < C::NK; ++kk) qf[kk] = *reinterpret_cast<const bf16x8*>(qrow + 16 * kk);
+    for (int kk = 0; kk < C::NK; ++kk) qf[kk] = *reinterpret_cast<const bf16x8*>(qblk + kk * 512);
   }
   const int64_t sid_i = P.sid_q[gi];
+  MI_FL_STAMP(11);
   // which streamed tiles hold a pair with equal study ids for this wave's rows (bit t: tile tile0 + t); the diagonal is
   // such a pair, so the positives only ever show up in flagged tiles
   unsigned long long dupmask;
@@ -371,6 +404,9 @@ __global__ __launch_bounds__(256, 1) void bilinear_flash_kernel(FlashArgs args) 
   const int lr = lane / C::CPR;
   const unsigned vlane = (unsigned)(lr * C::RB + 16 * ((lane % C::CPR) ^ (C::RPP > 1 ? (lr << 2) : 0)));
   auto issue_piece = [&](int t, int i) __attribute__((always_inline)) {
+#ifdef MI_STAMPS
+    if ((args.diag & 1) && t >= 3) return;
+#endif
     const int q = C::PIECES * wave + i;
     const int u = C::RPP == 1 ? fl_swz(q) : (C::RPP == 2 ? (8 * (q & 1)) | ((q >> 1) & 3) : (q & 3));
     const int stage = t & (kFlStages - 1);
@@ -380,15 +416,25 @@ __global__ __launch_bounds__(256, 1) void bilinear_flash_kernel(FlashArgs args) 
 #pragma unroll
     for (int i = 0; i < C::PIECES; ++i) issue_piece(t, i);
   };
+  MI_FL_STAMP(12);
   if (nt > 0) issue_tile(0);
   if (nt > 1) issue_tile(1);
   if (nt > 2) issue_tile(2);
+  MI_FL_STAMP(13);
 
   // streamed study ids of this split -> LDS (plain loads: done before the pipeline's counted waits start)
   {
+    // all loads first, then the LDS writes: as a plain copy loop hipcc waited for each load before its store, four to
+    // eight dependent L2 round trips in the prologue of every workgroup
     int64_t* sl = reinterpret_cast<int64_t*>(smem + C::SID_OFF);
     const int64_t* sg = P.sid_kv + tile0 * kFlBN;
-    for (int e = tid; e < nt * kFlBN; e += 256) sl[e] = sg[e];
+    constexpr int PER = kFlMaxTilesPerSplit * kFlBN / 256;
+    int64_t v[PER];
+#pragma unroll
+    for (int k = 0; k < PER; ++k) v[k] = tid + 256 * k < nt * kFlBN ? sg[tid + 256 * k] : 0;
+#pragma unroll
+    for (int k = 0; k < PER; ++k)
+      if (tid + 256 * k < nt * kFlBN) sl[tid + 256 * k] = v[k];
   }
 
   constexpr int NO = GRAD ? C::NT : 1;
@@ -412,9 +458,14 @@ __global__ __launch_bounds__(256, 1) void bilinear_flash_kernel(FlashArgs args) 
 
   // the Q loads, the id copy and the first tiles must have landed (the asm-issued LDS-DMA is invisible to hipcc's own
   // wait insertion: drain it by hand)
+  MI_FL_STAMP(14);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  MI_FL_STAMP(15);
   __syncthreads();
   MI_FL_STAMP(1);
+  // first "use" of the plain loads here, so that hipcc places their vmcnt wait in the prologue and not at the first
+  // compare of the general mask path inside the loop (where it would drain the LDS-DMA prefetch)
+  asm volatile("" ::"v"(sid_i), "s"(dupmask));
   // pin the register classes once: from here on only the asm MFMAs touch these values
   fl_static_for<0, C::NK>([&](auto KK) __attribute__((always_inline)) { fl_pin<(decltype(KK)::value < C::QA)>(qf[decltype(KK)::value]); });
   if constexpr (GRAD) fl_static_for<0, C::NT>([&](auto CT) __attribute__((always_inline)) { fl_pin_o<(decltype(CT)::value < C::OA)>(o[decltype(CT)::value]); });
@@ -429,6 +480,9 @@ __global__ __launch_bounds__(256, 1) void bilinear_flash_kernel(FlashArgs args) 
   constexpr int NSL = 32;
   auto sm_slice = [&](auto SI, int tp) __attribute__((always_inline)) {
     constexpr int si = decltype(SI)::value;
+#ifdef MI_STAMPS
+    if (args.diag & 2) return;
+#endif
     if constexpr (si == 0) {
       if (__builtin_amdgcn_readfirstlane((int)((dupmask >> tp) & 1ull))) {
         // some pair of this tile shares a study id (always so on the diagonal): exact 64-bit compares, positives
@@ -549,6 +603,10 @@ __global__ __launch_bounds__(256, 1) void bilinear_flash_kernel(FlashArgs args) 
       if (t == nt / 2) MI_FL_STAMP(2);
       // tile t + 1 must have landed (own pieces, then everybody's); every wave is done with tile t - 1, whose stage the
       // pieces issued in this iteration refill.  Outstanding here: tiles t + 1 and t + 2.
+#ifdef MI_STAMPS
+      if (args.diag & 4) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      else
+#endif
       if (t + 2 < nt) fl_wait_vmcnt_barrier<C::PIECES>();
       else fl_wait_vmcnt_barrier<0>();
       if (t == nt / 2) MI_FL_STAMP(3);
@@ -657,6 +715,7 @@ struct FlashReduceArgs {
 
 template <int D>
 __global__ __launch_bounds__(256) void flash_reduce_kernel(FlashReduceArgs args) {
+  kernarg_prefetch<(int)sizeof(FlashReduceArgs)>();
   __shared__ float tile[32][129];
   const FlashReduceJob& J = args.j[blockIdx.z];
   const int64_t wb = blockIdx.y;  // 32-row block
@@ -798,6 +857,10 @@ static inline int launch_flash_t(const FlashArgs& a, unsigned grid, hipStream_t 
 static inline int launch_flash(FlashArgs a, int64_t d, bool grad, hipStream_t st, const char* what) {
   int combos = a.p[0].n_split + (a.n_problems == 2 ? a.p[1].n_split : 0);
   a.n_combo = (combos + 7) / 8 * 8;
+  a.diag = 0;
+#ifdef MI_STAMPS
+  if (const char* e = getenv("MI_FLASH_DIAG")) a.diag = atoi(e);
+#endif
   int max_rb = a.p[0].n_rb;
   if (a.n_problems == 2 && a.p[1].n_rb > max_rb) max_rb = a.p[1].n_rb;
   const unsigned grid = (unsigned)(a.n_combo * max_rb);

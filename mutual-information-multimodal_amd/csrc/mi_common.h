@@ -154,6 +154,20 @@ __device__ __forceinline__ Partial block_reduce_partial(Partial p, Partial* scra
   return p;
 }
 
+// Touch every 64-byte line of the kernel-argument segment in ONE batch of independent scalar loads.  The segment is
+// cold when a kernel starts and hipcc reads struct arguments lazily, field by field behind branches: the small-GEMM
+// kernel went through 11 DEPENDENT scalar-load waits before its first memory operation, the fused bilinear kernel
+// through 5 (~11,000 cycles per workgroup in the in-kernel stamps).  After this call those loads hit the scalar cache.
+template <int BYTES>
+__device__ __forceinline__ void kernarg_prefetch() {
+  const __attribute__((address_space(4))) unsigned* p =
+      (const __attribute__((address_space(4))) unsigned*)__builtin_amdgcn_kernarg_segment_ptr();
+  unsigned acc = 0;
+#pragma unroll
+  for (int o = 0; o < BYTES; o += 64) acc |= p[o / 4];
+  asm volatile("" ::"s"(acc));
+}
+
 // d loss / d score of one pair given the global statistics.
 // kind: 0 dropped, 1 positive (diagonal), 2 negative.
 __device__ __forceinline__ int pair_kind(int64_t gi, int64_t gj, int64_t sid_i, int64_t sid_j) {

@@ -130,7 +130,15 @@ struct EpiOut {
   int64_t ld_bf;
   bf16_t* bf_t;         // transposed [N][ld_bf_t] or null
   int64_t ld_bf_t;
+  bf16_t* bf_frag;      // fragment-major copy or null (needs M % 32 == 0, N % 16 == 0): the 8 elements
+                        // [row][16 kk + 8 h .. + 7] sit at ((row / 32 * (N / 16) + kk) * 64 + 32 h + row % 32) * 8, i.e. one
+                        // 1 KB block per (32-row block, 16-deep step) in the lane order of an MFMA 32x32x16 operand
 };
+
+__device__ __forceinline__ int64_t frag_major_offset(int64_t row, int64_t col8, int64_t n_cols) {
+  // col8: first column of an aligned group of 8
+  return (((row >> 5) * (n_cols >> 4) + (col8 >> 4)) * 64 + ((col8 >> 3) & 1) * 32 + (row & 31)) * 8;
+}
 
 template <class F>
 __device__ __forceinline__ void foreach_acc4(f32x16 (&acc)[2][2], int64_t m_base, int64_t n_base, F&& f) {
@@ -179,11 +187,11 @@ __device__ __forceinline__ void wave_lds_fence() {
 // with N % 8 == 0 (M % 8 == 0) happens in whole chunks.
 __device__ __forceinline__ void wave_tile_store_bf16(f32x16 (&acc)[2][2], char* lds, bf16_t* rm, int64_t ld_rm,
                                                      bf16_t* tr, int64_t ld_tr, int64_t mb, int64_t nb, int64_t M,
-                                                     int64_t N) {
+                                                     int64_t N, bf16_t* frag = nullptr) {
   const int lane = threadIdx.x & 63;
   const int col_l = lane & 31, half = lane >> 5;
   const int srow = lane >> 3, chunk = lane & 7;
-  if (rm) {
+  if (rm || frag) {
     wave_lds_fence();
 #pragma unroll
     for (int tm = 0; tm < 2; ++tm)
@@ -200,7 +208,10 @@ __device__ __forceinline__ void wave_tile_store_bf16(f32x16 (&acc)[2][2], char* 
       const int row_l = it * 8 + srow;
       const bf16x8 v = *reinterpret_cast<const bf16x8*>(lds + row_l * kEpiPitch + chunk * 16);
       const int64_t grow = mb + row_l, gcol = nb + chunk * 8;
-      if (grow < M && gcol < N) *reinterpret_cast<bf16x8*>(rm + grow * ld_rm + gcol) = v;
+      if (grow < M && gcol < N) {
+        if (rm) *reinterpret_cast<bf16x8*>(rm + grow * ld_rm + gcol) = v;
+        if (frag) *reinterpret_cast<bf16x8*>(frag + frag_major_offset(grow, gcol, N)) = v;
+      }
     }
   }
   if (tr) {
@@ -234,6 +245,7 @@ struct EpiStoreMulti {
                                              int zsplit, char* lds) const {
     const EpiOut& o = out[prob];
     const bool staged = (M % 8 == 0) && (N % 8 == 0) && (!o.bf || o.ld_bf % 8 == 0) && (!o.bf_t || o.ld_bf_t % 8 == 0);
+    // (a fragment-major output is only requested for shapes that take the staged path: M % 32 == 0, N % 16 == 0)
     if (o.f32 || (o.bf && !staged)) {
       float* f = o.f32 ? o.f32 + (int64_t)zsplit * o.slab_stride : nullptr;
       bf16_t* bfd = staged ? nullptr : o.bf;
@@ -245,7 +257,8 @@ struct EpiStoreMulti {
       });
     }
     if (staged) {
-      if (o.bf || o.bf_t) wave_tile_store_bf16(acc, lds, o.bf, o.ld_bf, o.bf_t, o.ld_bf_t, mb, nb, M, N);
+      if (o.bf || o.bf_t || o.bf_frag)
+        wave_tile_store_bf16(acc, lds, o.bf, o.ld_bf, o.bf_t, o.ld_bf_t, mb, nb, M, N, o.bf_frag);
     } else if (o.bf_t) {
       foreach_acc4(acc, mb, nb, [&](int64_t row0, int64_t col, float v0, float v1, float v2, float v3) {
         if (col < N) store4_transposed(o.bf_t, o.ld_bf_t, row0, col, M, v0, v1, v2, v3);
@@ -443,6 +456,7 @@ struct EpiGradScore2 {
 
 template <class Epi>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmBf16Args args, Epi epi) {
+  kernarg_prefetch<(int)(sizeof(GemmBf16Args) + sizeof(Epi))>();
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   bf16_t* As = reinterpret_cast<bf16_t*>(smem_raw);      // [2][128][72]
   bf16_t* Bs = As + 2 * kTile * kG2LD;                    // [2][128][72]
@@ -539,6 +553,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmBf16Args args, Ep
 // K = d, next to dW = X^T dT, split 16 ways over K = B); each problem owns a contiguous range of workgroup ids.
 template <class Epi>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_glds_kernel(GemmBf16Args args, Epi epi) {
+  kernarg_prefetch<(int)(sizeof(GemmBf16Args) + sizeof(Epi))>();
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   // [buf][A | B][128 rows][128 bytes]
   int prob, zsplit, bx_, by_;
@@ -697,6 +712,7 @@ __device__ __forceinline__ void wait_vmcnt_barrier() {
 
 template <class Cfg, class Epi>
 __global__ __launch_bounds__(512, 1) void gemm_bf16_pipe_kernel(GemmBf16Args args, Epi epi) {
+  kernarg_prefetch<(int)(sizeof(GemmBf16Args) + sizeof(Epi))>();
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   int prob, zsplit, bx_, by_;
   int64_t k_chunk = args.k_chunk;
@@ -897,6 +913,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_pipe_kernel(GemmBf16Args arg
 // 4096 x 4096 problem is exactly one workgroup per CU.  Single problem, no split-K.
 template <class Epi>
 __global__ __launch_bounds__(512, 1) void gemm_bf16_big_kernel(GemmBf16Args args, Epi epi) {
+  kernarg_prefetch<(int)(sizeof(GemmBf16Args) + sizeof(Epi))>();
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   // [buf][A | B][256 rows][128 bytes]
   const GemmBf16Problem& P = args.p[0];
@@ -1167,14 +1184,63 @@ struct CvtJob {
   bf16_t* out_t;
   int n_slab;           // > 1: in holds n_slab partial sums [n_slab][R][C], added in slab order before the conversion
   int64_t slab_stride;  // elements between slabs
+  bf16_t* out_frag;     // fragment-major copy (see EpiOut::bf_frag; R % 32 == 0, C % 16 == 0) or null
+};
+// equal-id flags of the fused bilinear kernel, computed by spare workgroups of the conversion launch (blockIdx.z == 3)
+struct DupFlagJob {
+  const int64_t* sid_rows;
+  const int64_t* sid_cols;
+  int na, nb;              // 32-row blocks of the two id lists; na == 0: no job
+  unsigned char* flag;     // [na][nb]
+  unsigned char* flag_t;   // [nb][na]
 };
 struct CvtJobs {
   CvtJob j[3];
+  DupFlagJob dup;
 };
+
+// flag[a][b] = 1 iff some image row of block a and some text row of block b share a study id.  One call handles the 64
+// column blocks starting at b0 for row block a (256 threads: 4 per column block, 8 rows each); exact 64-bit compares.
+__device__ __forceinline__ void dup_flags_block(const DupFlagJob& J, int a, int b0, int64_t* rows_lds) {
+  const int tid = threadIdx.x;
+  if (tid < 32) rows_lds[tid] = J.sid_rows[a * 32 + tid];
+  __syncthreads();
+  const int q = tid & 3, b = b0 + (tid >> 2);
+  if (b < J.nb) {
+    int64_t mine[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) mine[e] = rows_lds[8 * q + e];
+    const int64_t* c = J.sid_cols + (int64_t)b * 32;
+    bool any = false;
+#pragma unroll 8
+    for (int j = 0; j < 32; ++j) {
+      const int64_t v = c[j];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) any |= v == mine[e];
+    }
+    int f = any ? 1 : 0;
+    f |= __shfl_xor(f, 1);
+    f |= __shfl_xor(f, 2);
+    if (q == 0) {
+      J.flag[(int64_t)a * J.nb + b] = (unsigned char)f;
+      J.flag_t[(int64_t)b * J.na + a] = (unsigned char)f;
+    }
+  }
+}
 // 64 x 64 tiles, 16-byte loads and 8-byte stores in both orientations (R % 4 == 0 and C % 4 == 0; 16-byte aligned
 // bases): 34 MB move per bilinear forward, ~10 us with 4-byte accesses on 32 x 32 tiles.
 static __global__ __launch_bounds__(256) void cvt_transpose3_kernel(CvtJobs jobs) {
+  kernarg_prefetch<(int)sizeof(CvtJobs)>();
   __shared__ float tile[64][65];
+  if (blockIdx.z == 3) {  // the equal-id flags ride along: (row block, 64 column blocks) pairs over this slice's blocks
+    const DupFlagJob& D = jobs.dup;
+    const int chunks = (D.nb + 63) / 64, total = D.na * chunks;
+    for (int w = (int)(blockIdx.y * gridDim.x + blockIdx.x); w < total; w += (int)(gridDim.x * gridDim.y)) {
+      dup_flags_block(D, w / chunks, (w % chunks) * 64, reinterpret_cast<int64_t*>(&tile[0][0]));
+      __syncthreads();
+    }
+    return;
+  }
   const CvtJob& J = jobs.j[blockIdx.z];
   const int64_t r0 = (int64_t)blockIdx.y * 64, c0 = (int64_t)blockIdx.x * 64;
   if (r0 >= J.R || c0 >= J.C) return;
@@ -1190,9 +1256,10 @@ static __global__ __launch_bounds__(256) void cvt_transpose3_kernel(CvtJobs jobs
     }
 #pragma unroll
     for (int e = 0; e < 4; ++e) tile[rl][4 * tx + e] = v[e];
-    if (J.out_rm && r < J.R && c < J.C) {
+    if ((J.out_rm || J.out_frag) && r < J.R && c < J.C) {
       const bf16x4 o = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
-      *reinterpret_cast<bf16x4*>(J.out_rm + r * J.C + c) = o;
+      if (J.out_rm) *reinterpret_cast<bf16x4*>(J.out_rm + r * J.C + c) = o;
+      if (J.out_frag) *reinterpret_cast<bf16x4*>(J.out_frag + frag_major_offset(r, c & ~(int64_t)7, J.C) + (c & 4)) = o;
     }
   }
   if (!J.out_t) return;
@@ -1240,12 +1307,16 @@ static inline int launch_cvt_transpose3(const CvtJobs& jobs, hipStream_t st, con
     if (J.R > rmax) rmax = J.R;
     if (J.C > cmax) cmax = J.C;
     vec = vec && J.R % 4 == 0 && J.C % 4 == 0 && (uintptr_t)J.in % 16 == 0 && (uintptr_t)J.out_rm % 8 == 0 &&
-          (uintptr_t)J.out_t % 8 == 0 && J.slab_stride % 4 == 0;
+          (uintptr_t)J.out_t % 8 == 0 && J.slab_stride % 4 == 0 && (!J.out_frag || (J.R % 32 == 0 && J.C % 16 == 0));
+  }
+  if (!vec && (jobs.dup.na > 0 || jobs.j[0].out_frag || jobs.j[1].out_frag || jobs.j[2].out_frag)) {
+    set_error("%s: fragment-major outputs / id flags need the vectorised conversion kernel (aligned, multiples of 4)", what);
+    return MI_ESHAPE;
   }
   {
     ProfScope prof_(what, st);
     if (vec) {
-      dim3 grid((unsigned)((cmax + 63) / 64), (unsigned)((rmax + 63) / 64), 3);
+      dim3 grid((unsigned)((cmax + 63) / 64), (unsigned)((rmax + 63) / 64), jobs.dup.na > 0 ? 4 : 3);
       hipLaunchKernelGGL(cvt_transpose3_kernel, grid, dim3(256), 0, st, jobs);
     } else {
       dim3 grid((unsigned)((cmax + 31) / 32), (unsigned)((rmax + 31) / 32), 3);

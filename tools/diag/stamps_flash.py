@@ -42,6 +42,12 @@ def seg(name, a, c):
     d_ = s[:, c] - s[:, a]
     print(f"{name:34s} median {np.median(d_):9.0f}  p10 {np.percentile(d_,10):9.0f}  p90 {np.percentile(d_,90):9.0f}")
 seg("prologue (entry -> first barrier)", 0, 1)
+seg("  Q loads issued", 0, 11)
+seg("  id flags (byte loads + ballot)", 11, 12)
+seg("  24 LDS-DMA pieces issued", 12, 13)
+seg("  id copy, accumulator init", 13, 14)
+seg("  s_waitcnt vmcnt(0)", 14, 15)
+seg("  barrier", 15, 1)
 seg("tile 0 scores + pipelined loop", 1, 8)
 seg("last tile (softmax + output product)", 8, 9)
 seg("epilogue (records + slab stores)", 9, 10)
