@@ -72,6 +72,7 @@ struct FlashArgs {
   FlashProblem p[2];
   int n_problems;
   int n_combo;  // (problem, split) pairs, padded to a multiple of 8
+  int xcd_rows; // 1: (problem, row block) units pinned to XCDs; 0: (problem, split) pairs pinned to XCDs
   int diag;     // diagnostic (MI_STAMPS) builds only, timing experiments with WRONG results: bit 0 no LDS-DMA in the loop,
                 // bit 1 no softmax slices, bit 2 no workgroup barrier in the loop (MI_FLASH_DIAG in the environment)
 };
@@ -334,16 +335,33 @@ __global__ __launch_bounds__(256, 1) void bilinear_flash_kernel(FlashArgs args) 
                "s"(Bp.n_split), "s"(Bp.tiles_per_split), "s"(Bp.dup), "s"(Bp.slab), "s"(Bp.rec), "s"(n_combo),
                "s"(n_problems));
   const int L = (int)blockIdx.x;
-  const int combo = L % n_combo, rb = L / n_combo;
-  int prob, split;
-  if (combo < A.n_split) {
-    prob = 0;
-    split = combo;
-  } else if (n_problems == 2 && combo < A.n_split + Bp.n_split) {
-    prob = 1;
-    split = combo - A.n_split;
+  int prob, split, rb;
+  if (args.xcd_rows) {
+    // a (problem, row block) unit and all its splits on ONE XCD (workgroups are dealt round-robin over the 8 XCDs:
+    // L % 8 labels the XCD): the stationary rows are then fetched into that XCD's L2 once for all splits.  With the other
+    // order -- a (problem, split) pair per XCD -- every XCD pulls a whole stationary operand through the fabric while its
+    // workgroups start (32 MB at B = 4096, d = 512: ~5 us, the in-kernel stamps of the prologue).  Speed only.
+    const int ns_max = A.n_split > Bp.n_split ? A.n_split : Bp.n_split;
+    const int x = L & 7, k = L >> 3;
+    const int unit = x + 8 * (k / ns_max);
+    split = k % ns_max;
+    const int n_units = A.n_rb + (n_problems == 2 ? Bp.n_rb : 0);
+    if (unit >= n_units) return;
+    prob = unit >= A.n_rb ? 1 : 0;
+    rb = prob ? unit - A.n_rb : unit;
+    if (split >= (prob ? Bp.n_split : A.n_split)) return;
   } else {
-    return;
+    const int combo = L % n_combo;
+    rb = L / n_combo;
+    if (combo < A.n_split) {
+      prob = 0;
+      split = combo;
+    } else if (n_problems == 2 && combo < A.n_split + Bp.n_split) {
+      prob = 1;
+      split = combo - A.n_split;
+    } else {
+      return;
+    }
   }
   FlashProblem P;
   P.q = prob ? Bp.q : A.q;
@@ -861,9 +879,16 @@ static inline int launch_flash(FlashArgs a, int64_t d, bool grad, hipStream_t st
 #ifdef MI_STAMPS
   if (const char* e = getenv("MI_FLASH_DIAG")) a.diag = atoi(e);
 #endif
+  static const int xcd_rows = getenv("MI_FLASH_XCD_COMBO") ? 0 : 1;  // A/B switch
+  a.xcd_rows = xcd_rows;
   int max_rb = a.p[0].n_rb;
   if (a.n_problems == 2 && a.p[1].n_rb > max_rb) max_rb = a.p[1].n_rb;
-  const unsigned grid = (unsigned)(a.n_combo * max_rb);
+  unsigned grid = (unsigned)(a.n_combo * max_rb);
+  if (a.xcd_rows) {
+    const int ns_max = a.n_problems == 2 && a.p[1].n_split > a.p[0].n_split ? a.p[1].n_split : a.p[0].n_split;
+    const int n_units = a.p[0].n_rb + (a.n_problems == 2 ? a.p[1].n_rb : 0);
+    grid = (unsigned)(8 * ((n_units + 7) / 8) * ns_max);
+  }
   if (d == 512) return grad ? launch_flash_t<512, true>(a, grid, st, what) : launch_flash_t<512, false>(a, grid, st, what);
   if (d == 256) return grad ? launch_flash_t<256, true>(a, grid, st, what) : launch_flash_t<256, false>(a, grid, st, what);
   if (d == 128) return grad ? launch_flash_t<128, true>(a, grid, st, what) : launch_flash_t<128, false>(a, grid, st, what);

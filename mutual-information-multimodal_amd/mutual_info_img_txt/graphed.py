@@ -1,0 +1,188 @@
+"""hipGraph replay of the fused MI step (single GPU), as a product API.
+
+The fused step is a handful of short kernels: at B = 4096 they take ~0.15 ms on the GPU while launching them one by one
+through Python, ctypes and the autograd engine takes longer than that on the host.  ``GraphedMiStep`` captures the C-ABI
+launches of one forward and of one backward into two hipGraphs, ONCE, for fixed shapes and fixed storage:
+
+* nothing of autograd is inside a capture (a backward captured through ``loss.backward()`` drags ``AccumulateGrad``
+  nodes of whatever stream created the leaves into the capture; that is how round 1's benchmark managed to abort inside
+  ``capture_end``).  The captures hold exactly the library calls of ``mi_critics.BilinearCriticFn`` /
+  ``ConcatMlpCriticFn``;
+* ``step()`` replays both graphs on the static buffers (benchmarks, custom loops);
+* ``loss(embedding_img, embedding_txt, study_id)`` returns a loss that is connected to autograd through a thin
+  ``torch.autograd.Function``: forward = copy the embeddings into the static buffers + replay graph 1, backward = copy
+  ``grad_output`` + replay graph 2 + hand the gradient buffers to autograd.  This is what ``MultiModalManager.train``
+  uses, so the trainer's step costs what the benchmark measures plus two small copies.
+
+The critic's parameters are read IN PLACE on every replay (optimizers update them in place): do not replace the
+``nn.Parameter`` objects' storage after building the step (``.to()`` the critic first).
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence
+
+import torch
+
+from . import _hip, mi_critics
+from .mi_critics import _concat_params, _estimator_code, _precision_code
+
+
+class GraphedMiStep:
+    def __init__(self, critic, batch_size: int, d_img: int, d_txt: int, estimator: str = "dv", precision: str = "f32",
+                 device=None, capture: bool = True):
+        from . import model as _model
+        self.device = torch.device(device if device is not None else "cuda")
+        if self.device.type != "cuda":
+            raise _hip.MiCriticError("GraphedMiStep needs a ROCm device (no CPU fallback)")
+        self.lib = _hip.load()
+        self.est, self.prec = _estimator_code(estimator), _precision_code(precision)
+        self.estimator = estimator
+        self.b, self.dx, self.dy = int(batch_size), int(d_img), int(d_txt)
+        dev = self.device
+        if isinstance(critic, _model.BilinearCritic):
+            self.kind = "bilinear"
+            self.params: List[torch.Tensor] = [critic.weight]
+        elif isinstance(critic, _model.SeparableCritic):
+            raise ValueError("SeparableCritic: project the embeddings first (its projections are ordinary modules) and "
+                             "build the step with critic=None on the projected widths")
+        elif critic is None:
+            if d_img != d_txt:
+                raise ValueError("critic=None is the separable form S = X Y^T: widths must agree")
+            self.kind = "bilinear"
+            self.params = []
+        else:
+            self.kind = "concat_mlp"
+            w1, b1, w2, b2, w3, b3 = _concat_params(critic)
+            self.params = [w1, b1, w2, b2, w3, b3]
+        for p in self.params:
+            if p.device != dev or p.dtype != torch.float32 or not p.is_contiguous():
+                raise ValueError("critic parameters must be contiguous float32 tensors on the step's device")
+        # static inputs
+        self.x = torch.zeros(self.b, self.dx, dtype=torch.float32, device=dev)
+        self.y = torch.zeros(self.b, self.dy, dtype=torch.float32, device=dev)
+        self.sid = torch.arange(self.b, dtype=torch.int64, device=dev)
+        self.grad_out = torch.ones(1, dtype=torch.float32, device=dev)
+        # static outputs
+        self.loss_buf = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.stats = _hip.new_stats(dev)
+        self.record = torch.zeros(_hip.RECORD_FLOATS, dtype=torch.float32, device=dev)
+        self.grad_x = torch.zeros_like(self.x)
+        self.grad_y = torch.zeros_like(self.y)
+        self.grad_params = [torch.zeros_like(p) for p in self.params]
+        if self.kind == "bilinear":
+            nbytes = self.lib.mi_bilinear_workspace_bytes(self.b, self.b, self.dx, self.dy, self.prec)
+        else:
+            self.h1, self.h2 = self.params[0].shape[0], self.params[2].shape[0]
+            if self.params[0].shape[1] != self.dx + self.dy:
+                raise ValueError("critic input width does not match d_img + d_txt")
+            nbytes = self.lib.mi_concat_mlp_workspace_bytes(self.b, self.b, self.dx, self.dy, self.h1, self.h2, self.prec, 1)
+            self.scores = torch.zeros(self.b, self.b, dtype=torch.float32, device=dev)
+        self.ws = _hip.workspace(nbytes, dev)
+        self.graph_fwd: Optional[torch.cuda.CUDAGraph] = None
+        self.graph_bwd: Optional[torch.cuda.CUDAGraph] = None
+        if capture:
+            self._capture()
+
+    # ------------------------------------------------------------------------------------------ raw C-ABI calls
+    def _w3_flat(self):
+        return self.params[4].reshape(-1)  # [1, h2] -> [h2], a view of the parameter's storage
+
+    def _fwd(self):
+        p = self.params
+        if self.kind == "bilinear":
+            _hip.call("mi_bilinear_fwd", self.device, self.x.data_ptr(), self.y.data_ptr(), p[0].data_ptr() if p else None,
+                      self.sid.data_ptr(), self.sid.data_ptr(), self.b, self.b, 0, self.dx, self.dy, self.est, self.prec, 1,
+                      self.loss_buf.data_ptr(), self.stats.data_ptr(), self.record.data_ptr(), None, self.ws.data_ptr(),
+                      self.ws.numel())
+        else:
+            _hip.call("mi_concat_mlp_fwd", self.device, self.x.data_ptr(), self.y.data_ptr(), p[0].data_ptr(),
+                      p[1].data_ptr(), p[2].data_ptr(), p[3].data_ptr(), p[4].data_ptr(), p[5].data_ptr(),
+                      self.sid.data_ptr(), self.sid.data_ptr(), self.b, self.b, 0, self.dx, self.dy, self.h1, self.h2,
+                      self.est, self.prec, 1, self.loss_buf.data_ptr(), self.stats.data_ptr(), self.record.data_ptr(),
+                      self.scores.data_ptr(), self.ws.data_ptr(), self.ws.numel())
+
+    def _bwd(self):
+        p, g = self.params, self.grad_params
+        if self.kind == "bilinear":
+            _hip.call("mi_bilinear_bwd", self.device, self.x.data_ptr(), self.y.data_ptr(), p[0].data_ptr() if p else None,
+                      self.sid.data_ptr(), self.sid.data_ptr(), self.b, self.b, 0, self.dx, self.dy, self.prec,
+                      self.stats.data_ptr(), self.grad_out.data_ptr(), self.grad_x.data_ptr(), self.grad_y.data_ptr(),
+                      g[0].data_ptr() if g else None, self.ws.data_ptr(), self.ws.numel(), 1)
+        else:
+            _hip.call("mi_concat_mlp_bwd", self.device, self.x.data_ptr(), self.y.data_ptr(), p[0].data_ptr(),
+                      p[1].data_ptr(), p[2].data_ptr(), p[3].data_ptr(), p[4].data_ptr(), p[5].data_ptr(),
+                      self.sid.data_ptr(), self.sid.data_ptr(), self.b, self.b, 0, self.dx, self.dy, self.h1, self.h2,
+                      self.prec, self.stats.data_ptr(), self.grad_out.data_ptr(), self.scores.data_ptr(),
+                      self.grad_x.data_ptr(), self.grad_y.data_ptr(), *[t.data_ptr() for t in g], self.ws.data_ptr(),
+                      self.ws.numel())
+
+    def _capture(self):
+        # warm-up on a side stream: module loading and the one-time kernel-attribute calls must not fall into a capture
+        side = torch.cuda.Stream(device=self.device)
+        side.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                self._fwd()
+                self._bwd()
+        torch.cuda.current_stream(self.device).wait_stream(side)
+        torch.cuda.synchronize(self.device)
+        self.graph_fwd = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph_fwd):
+            self._fwd()
+        self.graph_bwd = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph_bwd, pool=self.graph_fwd.pool()):
+            self._bwd()
+
+    # ------------------------------------------------------------------------------------------ replay
+    def forward(self) -> torch.Tensor:
+        """Loss of the static inputs (shape [1]; a view of the step's own buffer)."""
+        if self.graph_fwd is not None:
+            self.graph_fwd.replay()
+        else:
+            self._fwd()
+        return self.loss_buf
+
+    def backward(self) -> None:
+        """Gradients of ``grad_out * loss`` into ``grad_x``, ``grad_y``, ``grad_params`` (overwritten)."""
+        if self.graph_bwd is not None:
+            self.graph_bwd.replay()
+        else:
+            self._bwd()
+
+    def step(self) -> torch.Tensor:
+        self.forward()
+        self.backward()
+        return self.loss_buf
+
+    def set_inputs(self, embedding_img: torch.Tensor, embedding_txt: torch.Tensor, study_id=None) -> None:
+        self.x.copy_(embedding_img.detach())
+        self.y.copy_(embedding_txt.detach())
+        if study_id is not None:
+            self.sid.copy_(mi_critics.study_id_codes(study_id, self.device))
+
+    def loss(self, embedding_img: torch.Tensor, embedding_txt: torch.Tensor, study_id=None) -> torch.Tensor:
+        """Autograd-connected loss of one batch: shape [1] for "dv", [] for "infonce", as the reference."""
+        if tuple(embedding_img.shape) != (self.b, self.dx) or tuple(embedding_txt.shape) != (self.b, self.dy):
+            raise ValueError(f"GraphedMiStep was built for [{self.b},{self.dx}] / [{self.b},{self.dy}] embeddings")
+        if study_id is not None:
+            self.sid.copy_(mi_critics.study_id_codes(study_id, self.device))
+        out = _GraphedFn.apply(self, embedding_img, embedding_txt, *self.params)
+        return out if self.estimator == "dv" else out.reshape(())
+
+
+class _GraphedFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, step: GraphedMiStep, x, y, *params):
+        step.x.copy_(x)
+        step.y.copy_(y)
+        step.forward()
+        ctx.step = step
+        return step.loss_buf.clone()
+
+    @staticmethod
+    def backward(ctx, grad_loss):
+        step = ctx.step
+        step.grad_out.copy_(grad_loss.reshape(-1)[:1])
+        step.backward()
+        # clones: autograd may keep (or accumulate into) what it is handed, and the buffers are rewritten next step
+        return (None, step.grad_x.clone(), step.grad_y.clone(), *[g.clone() for g in step.grad_params])

@@ -16,13 +16,15 @@ yields embeddings directly, as ``train.py --synthetic`` does).
 from __future__ import annotations
 
 import logging
+import os
 import time
 from typing import Sequence
 
 import torch
 
 from . import _hip, mi_critics
-from .model import BilinearCritic, SeparableCritic, make_mlp
+from .model import (BilinearCritic, ImageReportModel, ResNet256_6_2_1, SeparableCritic, TextBert, build_bert_model,
+                    build_resnet_model, make_mlp)
 from .optimization import AdamW, WarmupLinearSchedule
 
 
@@ -82,13 +84,40 @@ def pair_index(study_id: Sequence, device):
 
 
 class MultiModalManager:
-    """Hot-path subset of the reference's MultiModalManager (main_utils.py:53-268)."""
+    """The reference's MultiModalManager (main_utils.py:53-268) around the MI355X critic path.
 
-    def __init__(self, d_img: int = 768, d_txt: int = 768, critic: str = "concat_mlp", hidden_dims=(1024, 512),
-                 d_proj: int = 256, image_model=None, text_model=None):
-        # optional encoders (the reference's self.model.image_model / text_model, model.py:540-555): any modules that
-        # map a batch to [B, d_img] / [B, d_txt] fp32 embeddings
+    Constructor: the reference's four arguments keep their names and order (``bert_pretrained_dir``, ``bert_config_name``,
+    ``output_channels``, ``image_model_name``, main_utils.py:58-59) and build the same objects: ``build_bert_model`` ->
+    ``self.text_model`` / ``self.bert_config``, ``build_resnet_model`` -> ``self.image_model``, ``ImageReportModel`` ->
+    ``self.model``, ``make_mlp(1536, [1024, 512])`` -> ``self.mi_discriminator``.  Keyword-only extensions: ready-made
+    encoder modules (``image_model=``, ``text_model=``: anything that maps a batch to ``[B, d]`` embeddings), the critic
+    kind / widths, projection heads (``embed_proj_dim``) and an autocast dtype for the encoders.  With no encoder at all
+    the manager trains the critic on embeddings handed in directly (``train.py --synthetic``)."""
+
+    def __init__(self, bert_pretrained_dir=None, bert_config_name=None, output_channels=None, image_model_name=None, *,
+                 d_img: int = 768, d_txt: int = 768, critic: str = "concat_mlp", hidden_dims=(1024, 512),
+                 d_proj: int = 256, image_model=None, text_model=None, bert_config=None, embed_proj_dim=None,
+                 autocast_dtype=None):
+        self.bert_pretrained_dir = bert_pretrained_dir
+        self.bert_config_name = bert_config_name
+        self.output_channels = output_channels
+        self.image_model_name = image_model_name
+        self.bert_config = bert_config
+        if bert_pretrained_dir is not None and bert_config_name is not None and text_model is None:
+            text_model, self.bert_config = build_bert_model(bert_pretrained_dir=bert_pretrained_dir,
+                                                            bert_config_name=bert_config_name,
+                                                            output_channels=output_channels)  # main_utils.py:65-68
+        if image_model_name is not None and image_model is None:
+            image_model = build_resnet_model(model_name=image_model_name,
+                                             output_channels=output_channels if output_channels is not None else 4)
         self.image_model, self.text_model = image_model, text_model
+        self.model = None
+        if isinstance(image_model, ResNet256_6_2_1) and isinstance(text_model, TextBert):
+            # the reference's joint model (main_utils.py:73-75); embeddings: z [B,768] and the pooled [CLS] after dropout
+            self.model = ImageReportModel(text_model=text_model, bert_config=self.bert_config, image_model=image_model,
+                                          proj_dim=embed_proj_dim, autocast_dtype=autocast_dtype)
+            d_img = embed_proj_dim or 768
+            d_txt = embed_proj_dim or getattr(self.bert_config, "hidden_size", 768)
         if critic == "concat_mlp":
             self.mi_discriminator = make_mlp(d_img + d_txt, list(hidden_dims))  # reference main_utils.py:77
         elif critic == "bilinear":
@@ -98,6 +127,9 @@ class MultiModalManager:
         else:
             raise ValueError(f"unknown critic {critic!r}: expected concat_mlp, bilinear or separable")
         self.critic_kind = critic
+        self.d_img, self.d_txt = d_img, d_txt
+        self.training_loss = []
+        self._graphed = None
         self.logger = logging.getLogger(__name__)
 
     def create_mi_pairs(self, embedding_img, embedding_txt, study_id: list, device=None):
@@ -109,10 +141,21 @@ class MultiModalManager:
             raise ValueError("embedding_img, embedding_txt and study_id must have the same length")
         return _CreatePairsFn.apply(embedding_img, embedding_txt, sid)
 
-    def mi_step(self, embedding_img, embedding_txt, study_id, mi_estimator: str = "dv", precision: str = "bf16",
-                fused: bool = True):
-        """Reference main_utils.py:220-224.  fused=False runs the literal three-call sequence (pair kernel, critic
-        module, bound kernel) and is only practical for small batches."""
+    def mi_step(self, embedding_img, embedding_txt, study_id, mi_estimator: str = "dv", precision: str = "f32",
+                fused: bool = True, graph: bool = False):
+        """Reference main_utils.py:220-224.  ``fused=False`` runs the literal three-call sequence (pair kernel, critic
+        module, bound kernel) and is only practical for small batches.  ``graph=True`` replays the fused step from
+        hipGraphs (``graphed.GraphedMiStep``, built on first use for this batch shape; the training loop's setting)."""
+        if fused and graph and self.critic_kind != "separable":
+            g = self._graphed
+            key = (tuple(embedding_img.shape), tuple(embedding_txt.shape), mi_estimator, precision)
+            if g is None or g.key != key:
+                from .graphed import GraphedMiStep
+                g = GraphedMiStep(self.mi_discriminator, embedding_img.shape[0], embedding_img.shape[1],
+                                  embedding_txt.shape[1], mi_estimator, precision, embedding_img.device)
+                g.key = key
+                self._graphed = g
+            return g.loss(embedding_img, embedding_txt, study_id)
         if fused:
             return mi_critics.fused_mi_bound(embedding_img, embedding_txt, study_id, self.mi_discriminator,
                                              mi_estimator, precision)
@@ -124,24 +167,83 @@ class MultiModalManager:
         critic = {"dv": mi_critics.dv_bound_loss, "infonce": mi_critics.infonce_bound_loss}[mi_estimator]
         return critic(mi_output, len(study_id), embedding_img.device)
 
-    def train(self, embedding_source, device, args):
+    # ------------------------------------------------------------------------------------------ batches
+    def _batches(self, source, device, args):
+        """One epoch of batches ``(img, txt, study_id)`` or ``(img, txt_ids, txt_masks, txt_segments, study_id, img_id)``.
+
+        ``source`` is (a) a callable ``step -> (img, txt, study_id)`` (synthetic embeddings / tests; ``steps_per_epoch``
+        of them), (b) a DataLoader-like iterable of the reference's 6-tuples (main_utils.py:192), or (c) the reference's
+        ``text_token_features`` list, from which the dataset and a shuffling ``drop_last`` DataLoader are built as at
+        main_utils.py:123-129 (``model_utils.build_training_imagereportset``)."""
+        if callable(source):
+            for step in range(int(args.steps_per_epoch)):
+                yield source(step)
+            return
+        if isinstance(source, (list, tuple)) and source and hasattr(source[0], "report_id"):
+            loader = getattr(self, "_loader", None)
+            if loader is None:
+                from .model_utils import build_training_imagereportset
+                dataset = build_training_imagereportset(text_token_features=source, img_dir=args.image_dir,
+                                                        img_size=getattr(args, "img_size", 256),
+                                                        dataset_metadata=args.dataset_metadata)
+                loader = torch.utils.data.DataLoader(dataset, batch_size=args.batch_size, shuffle=True,
+                                                     num_workers=getattr(args, "data_loader_workers", 0),
+                                                     pin_memory=True, drop_last=True)
+                print(f'Total number of training image-report pairs: {len(dataset)}')
+                self._loader = loader
+            source = loader
+        for batch in source:
+            yield batch
+
+    def _embed(self, batch, device):
+        """Batch -> (embedding_img, embedding_txt, study_id) through whatever encoders are attached."""
+        if len(batch) == 6:  # the reference's batch (main_utils.py:192, 201-204, 218-219)
+            img, txt_ids, txt_masks, txt_segments, study_id, _img_id = batch
+            img = img.to(device, non_blocking=True)
+            txt_ids = txt_ids.to(device, non_blocking=True)
+            txt_masks = txt_masks.to(device, non_blocking=True)
+            txt_segments = txt_segments.to(device, non_blocking=True)
+            if self.model is None:
+                raise ValueError("reference-style batches need the joint ImageReportModel (image + text encoders)")
+            embedding_img, embedding_txt, _logits_img, _logits_txt = self.model(img, txt_ids, txt_masks, txt_segments)
+            return embedding_img, embedding_txt, list(study_id)
+        img, txt, study_id = batch
+        embedding_img = self.image_model(img) if self.image_model is not None and self.model is None else img
+        embedding_txt = self.text_model(txt) if self.text_model is not None and self.model is None else txt
+        return embedding_img, embedding_txt, study_id
+
+    def train(self, text_token_features, device, args):
         """The reference's training loop (main_utils.py:112-268) around the fused MI step.
 
-        ``embedding_source(step) -> (img, txt, study_id)``: with encoders attached, ``img`` / ``txt`` are the encoders'
-        inputs (one batch, ``drop_last`` batching as main_utils.py:127-129); without, they are the embeddings.
-        Optimisers and order as the reference: Adam(image encoder, init_lr), Adam(critic, init_lr), AdamW(text encoder,
-        lr 2e-5, weight decay 0.1 except bias / LayerNorm, no bias correction) with a warm-up-linear schedule over
-        ``num_train_epochs * steps_per_epoch`` steps (10 % warm-up) -- main_utils.py:152-172; per step: zero_grad of
-        all three, forward, ``loss.backward()``, then critic, image, text optimiser steps and the scheduler step --
-        main_utils.py:205-229.  Epoch loss = sum of the step losses; the reference's two log lines per epoch."""
+        First argument: see ``_batches`` (the reference passes its ``text_token_features``).  Optimisers and order as the
+        reference: Adam(image encoder, init_lr), Adam(critic, init_lr), AdamW(text encoder, lr 2e-5, weight decay 0.1
+        except bias / LayerNorm, no bias correction) with a warm-up-linear schedule over ``num_train_epochs *
+        len(loader)`` steps, 10 % warm-up (main_utils.py:152-172); per step: zero_grad of all three, forward,
+        ``loss.backward()``, then critic, image, text optimiser steps and the scheduler step (main_utils.py:205-229).
+        Epoch loss = sum of the step losses.  Per epoch, with encoders attached and ``args.save_directory`` set: the
+        reference's three files (``pytorch_MI_image_model.bin``, ``pytorch_MI_text_model.bin``,
+        ``pytorch_model_epoch{n}.bin`` + BERT config, main_utils.py:242-245) and its log lines; additionally -- the
+        reference never saves the critic -- ``mi_critic_state.pt`` with the critic, the optimisers and the schedule for
+        resuming (a new file name, so the reference's loaders are unaffected).  Returns the list of epoch losses (the
+        reference returns None) and keeps it in ``self.training_loss``."""
         logger = logging.getLogger(__name__)
         mi_critics._estimator_code(args.mi_estimator)  # eager validation (the reference fails late, main_utils.py:224)
         self.mi_discriminator = self.mi_discriminator.to(device)
+        if self.model is not None:
+            self.model = self.model.to(device)
         mi_optimizer = torch.optim.Adam(self.mi_discriminator.parameters(), lr=args.init_lr)  # main_utils.py:153
         img_optimizer = txt_optimizer = scheduler = None
+        steps_per_epoch = int(getattr(args, "steps_per_epoch", 0) or 0)
+        if not callable(text_token_features) and hasattr(text_token_features, "__len__") and \
+                not (isinstance(text_token_features, (list, tuple)) and text_token_features
+                     and hasattr(text_token_features[0], "report_id")):
+            steps_per_epoch = len(text_token_features)
         if self.image_model is not None:
             self.image_model = self.image_model.to(device).train()
-            img_optimizer = torch.optim.Adam(self.image_model.parameters(), lr=args.init_lr)  # main_utils.py:152
+            img_params = list(self.image_model.parameters())
+            if self.model is not None and self.model.proj_img is not None:
+                img_params += list(self.model.proj_img.parameters()) + list(self.model.proj_txt.parameters())
+            img_optimizer = torch.optim.Adam(img_params, lr=args.init_lr)  # main_utils.py:152
         if self.text_model is not None:
             self.text_model = self.text_model.to(device).train()
             no_decay = ['bias', 'LayerNorm.bias', 'LayerNorm.weight']  # main_utils.py:158-165
@@ -149,23 +251,27 @@ class MultiModalManager:
             grouped = [{'params': [p for n, p in param_txt if not any(nd in n for nd in no_decay)], 'weight_decay': 0.1},
                        {'params': [p for n, p in param_txt if any(nd in n for nd in no_decay)], 'weight_decay': 0.0}]
             txt_optimizer = AdamW(grouped, lr=getattr(args, "txt_lr", 2e-5), correct_bias=False)
-            num_train_steps = int(args.num_train_epochs * args.steps_per_epoch)
+            num_train_steps = int(args.num_train_epochs * max(steps_per_epoch, 1))
             scheduler = WarmupLinearSchedule(txt_optimizer, warmup_steps=0.1 * num_train_steps, t_total=num_train_steps)
-        precision = getattr(args, "precision", "bf16")
-        training_loss = []
-        for epoch in range(int(args.num_train_epochs)):
+        precision = getattr(args, "precision", "f32")
+        use_graph = bool(getattr(args, "graph", True))
+        save_dir = getattr(args, "save_directory", None)
+        start_epoch = 0
+        resume = getattr(args, "resume_from", None)
+        if resume:
+            start_epoch = self.load_training_state(resume, mi_optimizer, img_optimizer, txt_optimizer, scheduler, device)
+        training_loss = self.training_loss = list(self.training_loss[:start_epoch])
+        for epoch in range(start_epoch, int(args.num_train_epochs)):
             start_time = time.time()
             epoch_loss = torch.zeros((), device=device)
-            for step in range(int(args.steps_per_epoch)):
-                img, txt, study_id = embedding_source(step)
+            for batch in self._batches(text_token_features, device, args):
                 if img_optimizer is not None:
                     img_optimizer.zero_grad()
                 if txt_optimizer is not None:
                     txt_optimizer.zero_grad()
                 mi_optimizer.zero_grad()
-                embedding_img = self.image_model(img) if self.image_model is not None else img
-                embedding_txt = self.text_model(txt) if self.text_model is not None else txt
-                loss = self.mi_step(embedding_img, embedding_txt, study_id, args.mi_estimator, precision)
+                embedding_img, embedding_txt, study_id = self._embed(batch, device)
+                loss = self.mi_step(embedding_img, embedding_txt, study_id, args.mi_estimator, precision, graph=use_graph)
                 loss.sum().backward()
                 mi_optimizer.step()
                 if img_optimizer is not None:
@@ -179,4 +285,64 @@ class MultiModalManager:
             interval = time.time() - start_time
             logger.info(f"  Epoch {epoch+1} loss = {epoch_loss:.5f}")
             logger.info(f"  Epoch {epoch+1} took {interval:.3f} s")
+            if save_dir:
+                if self.model is not None:  # main_utils.py:242-245 and the log lines :253-255
+                    image_model_file_path = self.model.save_image_model(save_dir)
+                    text_model_file_path = self.model.save_text_model(save_dir)
+                    checkpoint_path = self.model.save_pretrained(save_dir, epoch=epoch + 1)
+                    logger.info(f"  Epoch {epoch+1} checkpoint saved in {checkpoint_path}")
+                    logger.info(f"  Image model saved in {image_model_file_path}")
+                    logger.info(f"  Text model saved in {text_model_file_path}")
+                self.save_training_state(save_dir, epoch + 1, mi_optimizer, img_optimizer, txt_optimizer, scheduler)
+        if save_dir and training_loss:
+            _plot_losses(training_loss, os.path.join(save_dir, 'mutual_information_training.png'))  # main_utils.py:259-266
         return training_loss
+
+    # ------------------------------------------------------------------------------------------ resume (new capability)
+    CRITIC_STATE_FILE = 'mi_critic_state.pt'
+
+    def save_training_state(self, save_directory, epoch, mi_optimizer, img_optimizer=None, txt_optimizer=None,
+                            scheduler=None):
+        os.makedirs(save_directory, exist_ok=True)
+        state = {"epoch": int(epoch), "critic_kind": self.critic_kind, "training_loss": list(self.training_loss),
+                 "mi_discriminator": self.mi_discriminator.state_dict(), "mi_optimizer": mi_optimizer.state_dict(),
+                 "img_optimizer": None if img_optimizer is None else img_optimizer.state_dict(),
+                 "txt_optimizer": None if txt_optimizer is None else txt_optimizer.state_dict(),
+                 "scheduler": None if scheduler is None else {"last_epoch": scheduler.last_epoch}}
+        path = os.path.join(save_directory, self.CRITIC_STATE_FILE)
+        torch.save(state, path)
+        return path
+
+    def load_training_state(self, path, mi_optimizer, img_optimizer=None, txt_optimizer=None, scheduler=None,
+                            device=None) -> int:
+        """Restore what ``save_training_state`` wrote (tensors, numbers, lists and dicts only: loaded with
+        ``weights_only=True``).  Returns the number of finished epochs."""
+        if os.path.isdir(path):
+            path = os.path.join(path, self.CRITIC_STATE_FILE)
+        state = torch.load(path, map_location=device or 'cpu', weights_only=True)
+        self.mi_discriminator.load_state_dict(state["mi_discriminator"])
+        mi_optimizer.load_state_dict(state["mi_optimizer"])
+        if img_optimizer is not None and state.get("img_optimizer") is not None:
+            img_optimizer.load_state_dict(state["img_optimizer"])
+        if txt_optimizer is not None and state.get("txt_optimizer") is not None:
+            txt_optimizer.load_state_dict(state["txt_optimizer"])
+        if scheduler is not None and state.get("scheduler") is not None:
+            scheduler.last_epoch = int(state["scheduler"]["last_epoch"])
+        self.training_loss = list(state.get("training_loss", []))
+        return int(state["epoch"])
+
+
+def _plot_losses(training_loss, path):
+    """Loss curve of the reference (main_utils.py:259-266); skipped silently where matplotlib is unavailable."""
+    try:
+        import matplotlib
+        matplotlib.use("Agg")
+        from matplotlib import pyplot as plt
+    except Exception:
+        return
+    plt.xlabel('Epochs')
+    plt.ylabel('Value for Loss')
+    plt.plot(training_loss, label="train loss")
+    plt.legend()
+    plt.savefig(path)
+    plt.clf()

@@ -30,12 +30,11 @@ __all__ = ["dv_bound_loss", "infonce_bound_loss", "matrix_bound_loss", "fused_mi
 # study ids: list[str] in the reference (model_utils.py:212); compared with != only (main_utils.py:105)
 # ----------------------------------------------------------------------------------------------------------
 def study_id_codes(study_id: Union[Sequence, torch.Tensor], device) -> torch.Tensor:
-    """int64 device tensor with equal code <=> equal study id."""
-    if torch.is_tensor(study_id):
-        return study_id.to(device=device, dtype=torch.int64).contiguous()
-    table = {}
-    codes = [table.setdefault(s.item() if torch.is_tensor(s) else s, len(table)) for s in study_id]
-    return torch.tensor(codes, dtype=torch.int64, device=device)
+    """int64 device tensor with equal code <=> equal study id.  The codes are a pure function of each id
+    (``utils.study_id_to_int64``: the numeric value of ids like "50414267", a 62-bit hash otherwise), hence identical in
+    every process of a sharded run -- a first-seen numbering would not be."""
+    from .utils import study_ids_to_tensor
+    return study_ids_to_tensor(study_id, device)
 
 
 def _estimator_code(estimator: str) -> int:
@@ -257,7 +256,7 @@ def _concat_params(critic):
 
 
 def fused_mi_bound(embedding_img: torch.Tensor, embedding_txt: torch.Tensor, study_id, critic, estimator: str = "dv",
-                   precision: str = "bf16", return_scores: bool = False, return_stats: bool = False):
+                   precision: str = "f32", return_scores: bool = False, return_stats: bool = False):
     """Fused replacement of the reference lines main_utils.py:220-224:
 
         mi_input  = self.create_mi_pairs(embedding_img, embedding_txt, study_id, device)
@@ -267,11 +266,21 @@ def fused_mi_bound(embedding_img: torch.Tensor, embedding_txt: torch.Tensor, stu
     ``critic`` is the reference's ``make_mlp(d_img+d_txt,[h1,h2])`` nn.Sequential, or a ``BilinearCritic`` /
     ``SeparableCritic`` from ``mutual_info_img_txt.model`` (extensions).  Returns the loss (shape [1] for "dv",
     [] for "infonce", as the reference) and optionally the [B,B] score matrix S[i,j] = critic(img_i, txt_j).
+
+    ``precision`` defaults to "f32" (exact fp32 products on the fp32-input MFMA): the reference critic is fp32
+    throughout and this is the mode whose gradients match it.  "bf16" (bf16 MFMA operands, fp32
+    accumulate) is the fast mode; it moves the gradients of this heavily cancelling loss by up to a few percent of
+    max|grad| against the fp32 reference and must be asked for explicitly.  Embeddings in float64 are cast to float32
+    (the reference would run them in fp64; this path computes in fp32).
     """
     from . import model as _model  # local import: model.py imports nothing from here
 
     _hip.require_device(embedding_img, "embedding_img")
     _hip.require_device(embedding_txt, "embedding_txt")
+    if embedding_img.dtype == torch.float64:
+        embedding_img = embedding_img.float()
+    if embedding_txt.dtype == torch.float64:
+        embedding_txt = embedding_txt.float()
     code = _estimator_code(estimator)
     prec = _precision_code(precision)
     if embedding_img.dim() != 2 or embedding_txt.dim() != 2 or embedding_img.shape[0] != embedding_txt.shape[0]:

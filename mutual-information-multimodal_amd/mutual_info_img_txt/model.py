@@ -8,6 +8,12 @@ import math
 import torch
 import torch.nn as nn
 
+# the encoder -> critic interface and the checkpoint formats live in encoders.py; re-exported here because the reference
+# keeps them in model.py (`from mutual_info_img_txt.model import build_resnet_model, build_bert_model, ImageReportModel`)
+from .encoders import (BasicBlock, ImageReportModel, ProjectionHead, ResNet256_6_2_1, TextBert,  # noqa: F401
+                       build_bert_model, build_resnet256_6_2_1, build_resnet_model, conv1x1, conv3x3,
+                       convert_legacy_keys, image_state_from_checkpoint)
+
 
 def make_mlp(input_dim, hidden_dims: list, output_dim=1, activation='relu'):
     """Same contract as the reference's make_mlp (model.py:18-32): an nn.Sequential of Linear/ReLU pairs followed by a

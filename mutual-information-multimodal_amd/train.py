@@ -22,7 +22,12 @@ def construct_training_parameters(argv=None):
     p.add_argument('--embed_dim_img', default=128, type=int)
     p.add_argument('--embed_dim_txt', default=128, type=int)
     p.add_argument('--steps_per_epoch', default=20, type=int)
-    p.add_argument('--precision', default='bf16', choices=['bf16', 'f32'])
+    p.add_argument('--precision', default='f32', choices=['bf16', 'f32'])  # the reference is fp32; bf16 is the fast mode
+    p.add_argument('--synthetic_encoders', action='store_true')
+    p.add_argument('--img_size', default=256, type=int)                        # helpers.py:130
+    p.add_argument('--output_channels', default=1, type=int)                   # helpers.py:131
+    p.add_argument('--embed_proj_dim', default=None, type=int)
+    p.add_argument('--no_graph', dest='graph', action='store_false')
     p.add_argument('--seed', default=0, type=int)
     return p.parse_args(argv)
 
@@ -35,7 +40,8 @@ def train_MI_models(argv=None):
         raise RuntimeError("the MI critic path needs an MI355X (ROCm) device; there is no CPU fallback")
     device = torch.device('cuda')
     args.save_directory = os.path.join(args.save_directory, f'mm_{args.mi_estimator}_epoch{args.num_train_epochs}')
-    manager, losses = train_mutual_information(args, device)
+    train_mutual_information(args, device)
+    losses = train_mutual_information.last_manager.training_loss
     for n, l in enumerate(losses):
         print(f'Epoch {n+1} finished! Epoch loss: {l:.5f}')
     return losses

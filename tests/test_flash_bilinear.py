@@ -130,7 +130,8 @@ def test_flash_no_negatives_and_single_block(dev):
     x, y = torch.randn(b, d, generator=gen), torch.randn(b, d, generator=gen)
     w = torch.eye(d)
     from mutual_info_img_txt import mi_critics
-    loss = mi_critics.fused_mi_bound(x.to(dev), y.to(dev), torch.zeros(b, dtype=torch.int64), _critic(dev, w), "infonce")
+    loss = mi_critics.fused_mi_bound(x.to(dev), y.to(dev), torch.zeros(b, dtype=torch.int64), _critic(dev, w), "infonce",
+                                     precision="bf16")
     assert not math.isfinite(float(loss))
 
 

@@ -1,0 +1,139 @@
+"""GraphedMiStep: hipGraph replay of the fused step (C-ABI calls captured directly, no autograd inside the capture)
+against the eager autograd path -- same kernels in the same order, so results must be bit-identical -- and the trainer /
+entry points on top of it, including the reference's encoders."""
+import math
+import os
+import types
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    from mutual_info_img_txt import _hip
+    _hip.load()
+    return torch.device("cuda:0")
+
+
+def _critic(kind, d, dev):
+    from mutual_info_img_txt.model import BilinearCritic, make_mlp
+    torch.manual_seed(5)
+    return (BilinearCritic(d, d) if kind == "bilinear" else make_mlp(2 * d, [128, 256])).to(dev)
+
+
+@pytest.mark.parametrize("kind,precision,b,d,est", [("bilinear", "bf16", 512, 256, "infonce"), ("bilinear", "f32", 96, 64, "dv"),
+                                                    ("concat_mlp", "f32", 96, 32, "dv"), ("concat_mlp", "bf16", 128, 64, "infonce")])
+def test_graphed_step_bit_identical_to_eager(dev, kind, precision, b, d, est):
+    from mutual_info_img_txt import mi_critics
+    from mutual_info_img_txt.graphed import GraphedMiStep
+    critic = _critic(kind, d, dev)
+    step = GraphedMiStep(critic, b, d, d, est, precision, dev)
+    gen = torch.Generator().manual_seed(b + d)
+    for trial in range(3):
+        x = torch.randn(b, d, generator=gen).to(dev)
+        y = torch.randn(b, d, generator=gen).to(dev)
+        sid = torch.randint(0, b, (b,), generator=gen)
+        with torch.no_grad():  # parameters are read in place: new contents, same storage
+            for p in critic.parameters():
+                p.add_(0.01 * (trial + 1))
+        # raw replay on the static buffers
+        step.set_inputs(x, y, sid)
+        loss = step.step().clone()
+        gx, gy = step.grad_x.clone(), step.grad_y.clone()
+        gp = [g.clone() for g in step.grad_params]
+        # the eager autograd path
+        xl, yl = x.clone().requires_grad_(True), y.clone().requires_grad_(True)
+        for p in critic.parameters():
+            p.grad = None
+        ref = mi_critics.fused_mi_bound(xl, yl, sid, critic, est, precision=precision)
+        ref.sum().backward()
+        torch.cuda.synchronize()
+        assert float(loss) == float(ref.sum())
+        assert torch.equal(gx, xl.grad) and torch.equal(gy, yl.grad)
+        for g, p in zip(gp, critic.parameters()):
+            assert torch.equal(g.reshape(p.shape), p.grad)
+        # through autograd: loss() is differentiable w.r.t. the embeddings (their producers) and the critic
+        xa, ya = x.clone().requires_grad_(True), y.clone().requires_grad_(True)
+        for p in critic.parameters():
+            p.grad = None
+        la = step.loss(xa * 1.0, ya * 1.0, sid)          # non-leaf inputs, as encoder outputs are
+        assert tuple(la.shape) == ((1,) if est == "dv" else ())
+        (2.0 * la.sum()).backward()                       # a non-unit grad_output reaches the captured backward
+        torch.cuda.synchronize()
+        scale = float(xl.grad.abs().max())
+        assert float((xa.grad - 2.0 * xl.grad).abs().max()) <= 1e-5 * scale
+        p0 = next(critic.parameters())
+        assert float((p0.grad - 2.0 * gp[0].reshape(p0.shape)).abs().max()) <= 1e-5 * float(gp[0].abs().max()) + 1e-12
+
+
+def test_trainer_uses_graphed_step_and_matches_eager(dev, tmp_path):
+    """MultiModalManager.train with graph replay on and off: identical loss trajectories (same kernels, same order)."""
+    from mutual_info_img_txt.main_utils import MultiModalManager
+    b, d = 64, 32
+    out = {}
+    for graph in (True, False):
+        torch.manual_seed(0)
+        mgr = MultiModalManager(d_img=d, d_txt=d, critic="concat_mlp", hidden_dims=(128, 256))
+        gen = torch.Generator().manual_seed(1)
+        base = torch.randn(b, d, generator=gen)
+
+        def source(step):
+            n = torch.randn(2, b, d, generator=gen) * 0.3
+            return (base + n[0]).to(dev), (base + n[1]).to(dev), [str(k) for k in range(b)]
+
+        args = types.SimpleNamespace(mi_estimator="dv", init_lr=1e-3, num_train_epochs=2, steps_per_epoch=8,
+                                     precision="f32", graph=graph, save_directory=str(tmp_path / f"g{int(graph)}"))
+        out[graph] = mgr.train(source, dev, args)
+        assert (mgr._graphed is not None) == graph
+        assert os.path.isfile(os.path.join(args.save_directory, "mi_critic_state.pt"))
+    assert out[True] == out[False] and out[True][-1] < out[True][0]
+
+
+def test_resume_continues_the_run(dev, tmp_path):
+    from mutual_info_img_txt.main_utils import MultiModalManager
+    b, d = 64, 16
+
+    def run(epochs, resume=None, save=None):
+        torch.manual_seed(0)
+        mgr = MultiModalManager(d_img=d, d_txt=d, critic="bilinear")
+        gen = torch.Generator().manual_seed(2)
+        data = [(torch.randn(b, d, generator=gen), torch.randn(b, d, generator=gen)) for _ in range(6)]
+
+        def source(step):
+            return data[step][0].to(dev), data[step][1].to(dev), list(range(b))
+
+        args = types.SimpleNamespace(mi_estimator="infonce", init_lr=1e-2, num_train_epochs=epochs, steps_per_epoch=6,
+                                     precision="f32", save_directory=save, resume_from=resume)
+        return mgr.train(source, dev, args)
+
+    full = run(3)
+    run(2, save=str(tmp_path))
+    resumed = run(3, resume=str(tmp_path))
+    assert len(resumed) == 3 and resumed[:2] == full[:2]
+    assert abs(resumed[2] - full[2]) <= 1e-4 * abs(full[2])
+
+
+def test_reference_encoders_end_to_end(dev, tmp_path):
+    """The reference's step with its own encoders (ResNet256_6_2_1 -> z [B,768]; BERT -> pooled [CLS] after dropout),
+    synthetic data: embeddings reach the fused critic, all three optimisers step, the reference's per-epoch files appear
+    and `train_mutual_information` returns the image model (multi_modal.py:67)."""
+    pytest.importorskip("transformers")
+    import multi_modal
+    args = types.SimpleNamespace(synthetic_encoders=True, batch_size=8, steps_per_epoch=3, num_train_epochs=2, img_size=256,
+                                 mi_estimator="dv", init_lr=1e-4, precision="f32", output_channels=1, seed=0,
+                                 save_directory=str(tmp_path), critic="concat_mlp", graph=True)
+    image_model = multi_modal.train_mutual_information(args, dev)
+    mgr = multi_modal.train_mutual_information.last_manager
+    from mutual_info_img_txt.model import ResNet256_6_2_1
+    assert isinstance(image_model, ResNet256_6_2_1) and image_model is mgr.image_model
+    assert len(mgr.training_loss) == 2 and all(math.isfinite(v) for v in mgr.training_loss)
+    for name in ("pytorch_MI_image_model.bin", "pytorch_MI_text_model.bin", "pytorch_model_epoch1.bin",
+                 "pytorch_model_epoch2.bin", "config.json", "mi_critic_state.pt", "training_MI.log"):
+        assert os.path.isfile(os.path.join(str(tmp_path), name)), name
+    log = open(os.path.join(str(tmp_path), "training_MI.log")).read()
+    for needle in ("Epoch 2 loss = ", "Epoch 2 took ", "Epoch 2 checkpoint saved in ", "Image model saved in ", "Text model saved in "):
+        assert needle in log
+    assert tuple(next(mgr.mi_discriminator.parameters()).shape) == (1024, 768 + 64)   # make_mlp(d_img + d_txt, [1024, 512])
