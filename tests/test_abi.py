@@ -66,7 +66,8 @@ def test_host_logic():
     from mutual_info_img_txt import mi_critics
     from mutual_info_img_txt.model import BilinearCritic, SeparableCritic, make_mlp
     codes = mi_critics.study_id_codes(["s1", "s2", "s1", "s3"], "cpu")
-    assert codes.tolist() == [0, 1, 0, 2] and codes.dtype == torch.int64
+    assert codes.dtype == torch.int64 and codes[0] == codes[2] and len(set(codes.tolist())) == 3
+    assert mi_critics.study_id_codes(["50000002", "50000001"], "cpu").tolist() == [50000002, 50000001]  # same on every rank
     mlp = make_mlp(1536, [1024, 512])
     assert list(mlp.state_dict().keys()) == ["0.weight", "0.bias", "2.weight", "2.bias", "4.weight", "4.bias"]
     w1, b1, w2, b2, w3, b3 = mi_critics._concat_params(mlp)
