@@ -7,17 +7,28 @@ Headline workload (BASELINE.json configs[3], the configuration its metric is quo
   global-batch "InfoNCE" (reference semantics, mi_critics.py:14-23), bilinear critic S = (X W) Y^T, B_global = 4096,
   d = 512, bf16 MFMA operands / fp32 accumulate, unique study ids, inputs resident in HBM.  With N GPUs the SAME global
   batch is sharded by row blocks (strong scaling) and the text embeddings are all-gathered over RCCL.
-Secondary workload in the same JSON line ("secondary"): the reference's own critic, make_mlp(2d,[1024,512]) concat-MLP.
+A step = pair enumeration + scorer + bound + ALL gradients (dX, dY, d theta) through the product API
+`graphed.GraphedMiStep` (one GPU) / `distributed.GlobalBatchGraphStep` (N GPUs): the C-ABI launches of the step,
+replayed from hipGraphs (`--graph off`: issued one by one).  Encoders, optimisers and data loading are not in the metric.
 
-One JSON line on stdout (rank 0) with the driver's contract plus "roofline" (dominant kernel, HIP-event timed through
-the library's profiling hook) and "cpu_baseline" (the oracle timed on this box's host cores, rank 0, N = 1 only).
+One JSON line on stdout (rank 0): the driver's contract (`value` from exactly K steps between barriers / synchronize),
+plus `timing` (median / p10 / p90 of >= 50 individually hipEvent-timed steps, graph and eager), `roofline` (dominant
+kernel, HIP-event timed through the library's profiling hook), `parity_mode` (the same step in the fp32 parity mode),
+`secondary` (the reference's own critic, make_mlp(2d,[1024,512])) and `cpu_baseline` (the oracle timed on this box's
+host cores, rank 0, N = 1 only).
 """
 import argparse
+import glob
+import hashlib
 import json
 import math
 import os
+import statistics
 import sys
 import time
+
+# multi-process GPU work on this pool needs dmabuf IPC: set before anything initialises HIP
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.join(ROOT, "mutual-information-multimodal_amd")
@@ -42,13 +53,14 @@ def parse_args():
     p.add_argument("--critic", default="bilinear", choices=["bilinear", "concat_mlp"])
     p.add_argument("--estimator", default="infonce", choices=["dv", "infonce"])
     p.add_argument("--precision", default="bf16", choices=["bf16", "f32"])
-    p.add_argument("--graph", default="auto", choices=["auto", "on", "off"],
-                   help="replay the step from hipGraphs (auto = on).  On one GPU the whole step is one graph; sharded "
-                        "over GPUs the two compute sections are graphs and the RCCL collectives stay eager between "
-                        "them.  Eagerly the bilinear step is bound by the host's launch rate, not by the GPU; for the "
-                        "concat-MLP step (51 ms of kernels) it makes no measurable difference")
+    p.add_argument("--graph", default="on", choices=["auto", "on", "off"],
+                   help="replay the step from hipGraphs (default).  One GPU: forward and backward graphs of "
+                        "GraphedMiStep; N GPUs: the two compute sections are graphs and the RCCL collectives stay eager "
+                        "between them.  off: the same C-ABI calls issued one by one (host-bound for the bilinear step)")
+    p.add_argument("--timed-iters", type=int, default=50, help="individually hipEvent-timed steps for the median (>= 50)")
     p.add_argument("--no-secondary", action="store_true")
     p.add_argument("--secondary-steps", type=int, default=5)
+    p.add_argument("--no-parity-mode", action="store_true")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-seconds", type=float, default=15.0)
     p.add_argument("--profile-steps", type=int, default=5)
@@ -65,7 +77,7 @@ def make_inputs(batch, d_img, d_txt, seed, rank, world, device):
     br = batch // world
     sl = slice(rank * br, (rank + 1) * br)
     sid = torch.arange(batch, dtype=torch.int64)
-    return x[sl].to(device), y[sl].to(device), sid[sl].to(device), (x, y)
+    return x[sl].to(device), y[sl].to(device), sid[sl].to(device)
 
 
 def make_critic(kind, d_img, d_txt, seed, device):
@@ -76,14 +88,6 @@ def make_critic(kind, d_img, d_txt, seed, device):
     else:
         m = make_mlp(d_img + d_txt, [1024, 512])  # reference main_utils.py:77 with 2d inputs
     return m.to(device)
-
-
-def critic_params(kind, critic):
-    from mutual_info_img_txt.mi_critics import _concat_params
-    if kind == "bilinear":
-        return [critic.weight]
-    w1, b1, w2, b2, w3, b3 = _concat_params(critic)
-    return [w1, b1, w2, b2, w3.reshape(-1), b3]
 
 
 def algorithmic_flops(kind, b, d_img, d_txt, h1=1024, h2=512):
@@ -108,7 +112,7 @@ def kernel_flops(name, br, b, d_img, d_txt, h1=1024, h2=512):
             return 4.0 * br * b * d_txt
         if any(t in name for t in ("score+LSE", "bilinear G", "dT = G Y", "dY = G^T T")):
             return 2.0 * br * b * d_txt
-        if "prep" in name or "slabs" in name:
+        if "prep" in name or "slabs" in name or "flags" in name:
             return 0.0
         return 2.0 * br * d_img * d_txt
     if name in ("concat_fwd_kernel", "concat_bwd_duv_kernel", "concat_bwd_dw2_kernel"):
@@ -121,81 +125,50 @@ def kernel_flops(name, br, b, d_img, d_txt, h1=1024, h2=512):
 
 
 class Stepper:
-    """One critic forward + backward through the public (autograd) API; optionally replayed from a hipGraph."""
+    """One critic forward + backward through the product API (no autograd anywhere in the timed path)."""
 
-    def __init__(self, kind, args, rank, world, device, group):
-        from mutual_info_img_txt import mi_critics
-        from mutual_info_img_txt.distributed import global_batch_mi_bound
+    def __init__(self, kind, args, rank, world, device, group, precision=None, graph=True):
+        from mutual_info_img_txt.graphed import GraphedMiStep
         self.kind, self.world, self.device = kind, world, device
         d = args.dim
-        self.x, self.y, self.sid, self.full = make_inputs(args.batch, d, d, 3, rank, world, device)
+        precision = precision or args.precision
+        x, y, sid = make_inputs(args.batch, d, d, 3, rank, world, device)
         self.critic = make_critic(kind, d, d, 3, device)
-        # built per use: a cached w3.reshape(-1) keeps an autograd view (and w3's AccumulateGrad node, bound to the
-        # stream of this constructor) alive, which breaks the capture of a later backward
-        self.params_fn = lambda: critic_params(kind, self.critic)
-        self.x.requires_grad_(True)
-        self.y.requires_grad_(True)
-        self.args = args
-        self.graph = None
-        self.staged = None
-        self.dist_mode = not (world == 1 and not os.environ.get("MI_BENCH_FORCE_DIST"))
-        if world == 1 and not os.environ.get("MI_BENCH_FORCE_DIST"):
-            self._loss = lambda: mi_critics.fused_mi_bound(self.x, self.y, self.sid, self.critic, args.estimator,
-                                                           precision=args.precision)
+        self.dist_mode = world > 1 or bool(os.environ.get("MI_BENCH_FORCE_DIST"))
+        self.graph_used = bool(graph)
+        if self.dist_mode:
+            from mutual_info_img_txt.distributed import GlobalBatchGraphStep
+            from mutual_info_img_txt.mi_critics import _concat_params
+            params = [self.critic.weight] if kind == "bilinear" else list(_concat_params(self.critic))
+            if kind != "bilinear":
+                params[4] = params[4].reshape(-1)
+            self.step_obj = GlobalBatchGraphStep(x, y, sid, [p.detach() for p in params], args.estimator, precision,
+                                                 critic=kind, group=group, capture=bool(graph))
+            self.eager_obj = self.step_obj if not graph else None
         else:
-            self._loss = lambda: global_batch_mi_bound(self.x, self.y, self.sid, self.params_fn(), args.estimator,
-                                                       args.precision, critic=kind, group=group)
-        self.loss = None
-
-    def eager(self):
-        self.x.grad = None
-        self.y.grad = None
-        for p in self.critic.parameters():
-            p.grad = None
-        self.loss = self._loss()
-        self.loss.sum().backward()
-
-    def try_capture(self):
-        self.eager()
-        torch.cuda.synchronize()
-        self.loss = None
-        s = torch.cuda.Stream()
-        s.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(s):
-            for _ in range(2):
-                self.eager()
-        torch.cuda.current_stream().wait_stream(s)
-        torch.cuda.synchronize()
-        # drop the last autograd graph: its AccumulateGrad nodes are bound to the warm-up stream, and a backward that
-        # reuses them inside the capture synchronises with that (non-capturing) stream and takes the process down
-        self.loss = None
-        self.x.grad = None
-        self.y.grad = None
-        for p in self.critic.parameters():
-            p.grad = None
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
-            self.loss = self._loss()
-            self.loss.sum().backward()
-        self.graph = g
-
-    def try_staged(self, group):
-        """Sharded step with its two compute sections replayed from hipGraphs and the collectives eager between them."""
-        from mutual_info_img_txt.distributed import GlobalBatchGraphStep
-        self.staged = GlobalBatchGraphStep(self.x.detach(), self.y.detach(), self.sid,
-                                           [p.detach() for p in self.params_fn()], self.args.estimator,
-                                           self.args.precision, critic=self.kind, group=group)
+            self.step_obj = GraphedMiStep(self.critic, args.batch, d, d, args.estimator, precision, device, capture=bool(graph))
+            self.step_obj.set_inputs(x, y, sid)
+            self.eager_obj = self.step_obj
 
     def step(self):
-        if self.staged is not None:
-            self.loss = self.staged.step()
-        elif self.graph is not None:
-            self.graph.replay()
-        else:
-            self.eager()
+        return self.step_obj.step()
+
+    def eager_step(self):
+        """The same C-ABI calls issued one by one (per-kernel event profiling needs real launches)."""
+        o = self.step_obj
+        if self.dist_mode:
+            return o.step_eager()
+        o._fwd()
+        o._bwd()
+        return o.loss_buf
+
+    def loss(self):
+        o = self.step_obj
+        return float((o.loss if self.dist_mode else o.loss_buf).detach().float().sum().item())
 
 
 def timed_run(stepper, steps, warmup, world):
+    """The driver's contract: W warm-up steps, then EXACTLY K steps between barrier + synchronize, max over ranks."""
     for _ in range(warmup):
         stepper.step()
     if world > 1:
@@ -215,15 +188,47 @@ def timed_run(stepper, steps, warmup, world):
     return elapsed
 
 
+def event_timed(fn, iters):
+    """Each step individually bracketed by HIP events on the launch stream (torch's current stream is the stream the
+    library launches on).  Returns milliseconds per step."""
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
+    for a, b in ev:
+        a.record()
+        fn()
+        b.record()
+    torch.cuda.synchronize()
+    return [a.elapsed_time(b) for a, b in ev]
+
+
+def timing_summary(stepper, iters):
+    iters = max(50, int(iters))
+    out = {"iters": iters}
+    ms = sorted(event_timed(stepper.step, iters))
+    out["graph" if stepper.graph_used else "eager"] = {
+        "median_ms": round(statistics.median(ms), 5), "p10_ms": round(ms[int(0.1 * (iters - 1))], 5),
+        "p90_ms": round(ms[int(0.9 * (iters - 1))], 5)}
+    if stepper.graph_used and stepper.eager_obj is not None:
+        for _ in range(3):
+            stepper.eager_step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(20):
+            stepper.eager_step()
+        torch.cuda.synchronize()
+        out["eager"] = {"mean_ms": round((time.perf_counter() - t0) / 20 * 1e3, 5),
+                        "note": "the same C-ABI calls issued one by one from Python: host-bound"}
+    return out
+
+
 def profile_kernels(stepper, steps):
     from mutual_info_img_txt import _hip
-    graph, stepper.graph = stepper.graph, None  # events need eager launches
-    stepper.eager()
+    if stepper.eager_obj is None and not stepper.dist_mode:
+        return {}
+    stepper.eager_step()
     torch.cuda.synchronize()
     with _hip.kernel_profile() as prof:
         for _ in range(steps):
-            stepper.eager()
-    stepper.graph = graph
+            stepper.eager_step()
     return prof.by_name()
 
 
@@ -239,25 +244,38 @@ PMC_KERNEL_OF = {
 }
 
 
-def measured_traffic(name, b, d):
-    """HBM bytes per launch of a kernel from the newest committed PMC pass (tools/profile_round.sh; FETCH_SIZE and
-    WRITE_SIZE in separate rocprofv3 --pmc runs, gfx950 corrections applied there).  Only valid for the configuration
-    those passes ran (B=4096, d=512, one GPU); None otherwise -- bench.py itself cannot run the profiler."""
+def csrc_sha():
+    """Fingerprint of the kernel sources: a committed PMC pass is only valid for the sources it profiled."""
+    h = hashlib.sha1()
+    for f in sorted(glob.glob(os.path.join(PKG, "csrc", "*.h")) + glob.glob(os.path.join(PKG, "csrc", "*.hip"))):
+        with open(f, "rb") as fh:
+            h.update(os.path.basename(f).encode() + b"\0" + fh.read())
+    return h.hexdigest()[:12]
+
+
+def measured_counters(name, b, d):
+    """HBM bytes per launch and MFMA-busy fraction of a kernel from the newest committed PMC pass
+    (tools/profile_round.sh: FETCH_SIZE, WRITE_SIZE and the SQ counters in separate rocprofv3 --pmc runs, gfx950
+    corrections applied there).  bench.py cannot run the profiler itself; it REFUSES a pass whose recorded source
+    fingerprint differs from the sources of this build (a stale pass would silently describe other kernels), and only
+    accepts the configuration those passes ran (B=4096, d=512, one GPU)."""
     if (b, d) != (4096, 512) or name not in PMC_KERNEL_OF:
         return None
-    import glob
-    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*_pmc_traffic.json")))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
     if not files:
         return None
     try:
         with open(files[-1]) as f:
-            table = json.load(f)["kernels"]
-    except (OSError, ValueError, KeyError):
+            doc = json.load(f)
+    except (OSError, ValueError):
         return None
-    for key, val in table.items():
+    src = os.path.basename(files[-1])
+    if doc.get("csrc_sha") != csrc_sha():
+        return {"stale": True, "source": src, "note": "PMC pass predates the current kernel sources: not attached"}
+    for key, val in doc.get("kernels", {}).items():
         if PMC_KERNEL_OF[name] in key:
-            return {"bytes": round(val["total_bytes"]), "fetch": round(val["fetch_bytes"]),
-                    "write": round(val["write_bytes"]), "source": os.path.basename(files[-1])}
+            return {"bytes": round(val["total_bytes"]), "fetch": round(val["fetch_bytes"]), "write": round(val["write_bytes"]),
+                    "mfma_busy_frac": val.get("mfma_busy_frac"), "source": src, "commit": doc.get("commit")}
     return None
 
 
@@ -272,9 +290,11 @@ def roofline_of(kernels, br, b, d, precision):
                 "traffic": None, "avg_us": k["ms_avg"] * 1e3}
     achieved = fl / (k["ms_avg"] * 1e-3) / 1e12
     peak = PEAK_TFLOPS[precision]
-    tr = measured_traffic(name, b, d) if br == b else None
+    c = measured_counters(name, b, d) if br == b else None
+    ok = c is not None and not c.get("stale")
     return {"kernel": name, "bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
-            "frac": round(achieved / peak, 4), "traffic": tr["bytes"] if tr else None, "traffic_detail": tr,
+            "frac": round(achieved / peak, 4), "traffic": c["bytes"] if ok else None,
+            "mfma_busy_frac": c.get("mfma_busy_frac") if ok else None, "counters": c,
             "avg_us": round(k["ms_avg"] * 1e3, 2), "flops_per_launch": fl}
 
 
@@ -326,7 +346,6 @@ def main():
     device = torch.device("cuda", local_rank)
     group = None
     if world > 1 or os.environ.get("MI_BENCH_FORCE_DIST"):  # the latter: rehearse the RCCL path with one rank
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
@@ -335,36 +354,21 @@ def main():
         raise SystemExit("--batch must be divisible by the number of GPUs")
     from mutual_info_img_txt import _hip
     _hip.load()
-
-    def run(kind, steps, warmup):
-        st = Stepper(kind, args, rank, world, device, group)
-        graph_used = False
-        want_graph = args.graph in ("on", "auto")
-        if want_graph:
-            try:
-                if st.dist_mode:
-                    st.try_staged(group)
-                    graph_used = "staged"
-                else:
-                    st.try_capture()
-                    graph_used = True
-            except Exception as e:  # capture is an optimisation, not a requirement
-                if args.graph == "on":
-                    raise
-                st.graph = None
-                st.staged = None
-                torch.cuda.synchronize()
-                if rank == 0:
-                    print(f"[bench] hipGraph capture unavailable ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
-        elapsed = timed_run(st, steps, warmup, world)
-        kernels = profile_kernels(st, args.profile_steps)
-        loss = float(st.loss.detach().float().sum().item())
-        return st, elapsed, kernels, graph_used, loss
-
-    st, elapsed, kernels, graph_used, loss = run(args.critic, args.steps, args.warmup)
+    want_graph = args.graph in ("on", "auto")
     b, d, br = args.batch, args.dim, args.batch // world
+
+    def run(kind, steps, warmup, precision=None, timed_iters=0):
+        st = Stepper(kind, args, rank, world, device, group, precision=precision, graph=want_graph)
+        elapsed = timed_run(st, steps, warmup, world)
+        timing = timing_summary(st, timed_iters) if timed_iters else None
+        kernels = profile_kernels(st, args.profile_steps)
+        return st, elapsed, kernels, timing
+
+    st, elapsed, kernels, timing = run(args.critic, args.steps, args.warmup, timed_iters=args.timed_iters)
     ms = elapsed / args.steps * 1e3
     flops = algorithmic_flops(args.critic, b, d, d)
+    graph_mode = ("compute sections; collectives eager between them" if st.dist_mode else "forward graph + backward graph") \
+        if want_graph else "none"
     out = {
         "metric": "img-txt pairs/sec (MI critic fwd+bwd), global-batch InfoNCE",
         "value": round(b / (ms * 1e-3), 1),
@@ -382,10 +386,9 @@ def main():
                                f"{args.critic} critic fwd+bwd, B_global={b}, d={d}",
                    "global_batch": b, "embed_dim": d, "critic": args.critic, "estimator": args.estimator,
                    "parallelism": f"row-block sharding x{world}, RCCL all-gather of text embeddings" if world > 1 else "single GPU",
-                   "hip_graph": bool(graph_used),
-                   "graph_mode": {True: "whole step", "staged": "compute sections; collectives eager between them",
-                                  False: "none"}[graph_used]},
-        "loss": loss,
+                   "hip_graph": bool(want_graph), "graph_mode": graph_mode},
+        "loss": st.loss(),
+        "timing": timing,
         "step_algorithmic_tflops": round(flops / (ms * 1e-3) / 1e12, 2),
         "step_frac_of_peak": round(flops / (ms * 1e-3) / 1e12 / (PEAK_TFLOPS[args.precision] * world), 5),
         "roofline": roofline_of(kernels, br, b, d, args.precision),
@@ -393,22 +396,36 @@ def main():
     }
     del st
     torch.cuda.empty_cache()
+    if not args.no_parity_mode and args.precision != "f32":
+        # the same step in the mode whose results match the fp32 reference
+        try:
+            st2, el2, k2, _ = run(args.critic, max(3, args.steps // 10), 2, precision="f32")
+            ms2 = el2 / max(3, args.steps // 10) * 1e3
+            out["parity_mode"] = {"f32": {"ms_per_step": round(ms2, 4), "value": round(b / (ms2 * 1e-3), 1), "unit": "pairs/s",
+                                          "step_frac_of_peak": round(flops / (ms2 * 1e-3) / 1e12 / (PEAK_TFLOPS["f32"] * world), 5),
+                                          "peak": PEAK_TFLOPS["f32"], "loss": st2.loss(),
+                                          "note": "v_mfma_f32_32x32x2_f32: exact fp32 products, the mode tests/ holds to the "
+                                                  "fp32 tolerances of DESIGN.md section 2"}}
+            del st2
+        except Exception as e:
+            out["parity_mode"] = {"error": f"{type(e).__name__}: {e}"}
+        torch.cuda.empty_cache()
     if not args.no_secondary:
         other = "concat_mlp" if args.critic == "bilinear" else "bilinear"
         try:
-            st2, el2, k2, g2, loss2 = run(other, args.secondary_steps, 2)
-            ms2 = el2 / args.secondary_steps * 1e3
-            fl2 = algorithmic_flops(other, b, d, d)
+            st3, el3, k3, _ = run(other, args.secondary_steps, 2)
+            ms3 = el3 / args.secondary_steps * 1e3
+            fl3 = algorithmic_flops(other, b, d, d)
             out["secondary"] = {
                 "workload": f"{other} critic fwd+bwd, B_global={b}, d={d}" + (" (the reference's mi_discriminator)" if other == "concat_mlp" else ""),
-                "value": round(b / (ms2 * 1e-3), 1), "unit": "pairs/s", "ms_per_step": round(ms2, 4),
-                "steps": args.secondary_steps, "hip_graph": g2, "loss": loss2,
-                "step_algorithmic_tflops": round(fl2 / (ms2 * 1e-3) / 1e12, 2),
-                "step_frac_of_peak": round(fl2 / (ms2 * 1e-3) / 1e12 / (PEAK_TFLOPS[args.precision] * world), 5),
-                "roofline": roofline_of(k2, br, b, d, args.precision),
-                "kernels_us": {k: round(v["ms_avg"] * 1e3, 2) for k, v in sorted(k2.items(), key=lambda kv: -kv[1]["ms_total"])},
+                "value": round(b / (ms3 * 1e-3), 1), "unit": "pairs/s", "ms_per_step": round(ms3, 4),
+                "steps": args.secondary_steps, "hip_graph": bool(want_graph), "loss": st3.loss(),
+                "step_algorithmic_tflops": round(fl3 / (ms3 * 1e-3) / 1e12, 2),
+                "step_frac_of_peak": round(fl3 / (ms3 * 1e-3) / 1e12 / (PEAK_TFLOPS[args.precision] * world), 5),
+                "roofline": roofline_of(k3, br, b, d, args.precision),
+                "kernels_us": {k: round(v["ms_avg"] * 1e3, 2) for k, v in sorted(k3.items(), key=lambda kv: -kv[1]["ms_total"])},
             }
-            del st2
+            del st3
         except Exception as e:
             out["secondary"] = {"error": f"{type(e).__name__}: {e}"}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

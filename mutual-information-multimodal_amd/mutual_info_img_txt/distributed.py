@@ -56,12 +56,17 @@ class HipBilinearOps:
                                          stats.data_ptr())
         return loss, stats
 
-    def backward(self, saved, stats, grad_out):
+    def backward(self, saved, stats, grad_out, out=None):
+        """``out`` = (grad_x, grad_y_partial, [grad_params...]) preallocated buffers (e.g. views of one flat all-reduce
+        buffer); allocated here when None."""
         lib = _hip.load()
         x, y_all, w, sid_rows, sid_all, row_offset, precision, ws = saved
         br, dx = x.shape
         b, dy = y_all.shape
-        gx, gy, gw = torch.empty_like(x), torch.empty_like(y_all), torch.empty_like(w)
+        if out is None:
+            gx, gy, gw = torch.empty_like(x), torch.empty_like(y_all), torch.empty_like(w)
+        else:
+            gx, gy, (gw,) = out
         _hip.call("mi_bilinear_bwd", x.device, x.data_ptr(), y_all.data_ptr(), w.data_ptr(), sid_rows.data_ptr(),
                                        sid_all.data_ptr(), br, b, row_offset, dx, dy, precision, stats.data_ptr(),
                                        grad_out.data_ptr(), gx.data_ptr(), gy.data_ptr(), gw.data_ptr(), ws.data_ptr(),
@@ -92,14 +97,17 @@ class HipConcatMlpOps:
 
     merge = HipBilinearOps.merge
 
-    def backward(self, saved, stats, grad_out):
+    def backward(self, saved, stats, grad_out, out=None):
         lib = _hip.load()
         x, y_all, params, sid_rows, sid_all, row_offset, precision, scores, ws = saved
         br, dx = x.shape
         b, dy = y_all.shape
         h1, h2 = params[0].shape[0], params[2].shape[0]
-        gx, gy = torch.empty_like(x), torch.empty_like(y_all)
-        gp = [torch.empty_like(p) for p in params]
+        if out is None:
+            gx, gy = torch.empty_like(x), torch.empty_like(y_all)
+            gp = [torch.empty_like(p) for p in params]
+        else:
+            gx, gy, gp = out
         _hip.call("mi_concat_mlp_bwd", x.device, x.data_ptr(), y_all.data_ptr(), *[p.data_ptr() for p in params],
                                          sid_rows.data_ptr(), sid_all.data_ptr(), br, b, row_offset, dx, dy, h1, h2,
                                          precision, stats.data_ptr(), grad_out.data_ptr(), scores.data_ptr(),
@@ -132,6 +140,27 @@ def _reduce_scatter_rows(t: torch.Tensor, group) -> torch.Tensor:
     return out
 
 
+def flat_views(like: Sequence[torch.Tensor]):
+    """One contiguous buffer and per-tensor views into it: the parameter gradients of a step travel in ONE all-reduce
+    (six separate latency-bound collectives for the concat-MLP critic otherwise)."""
+    if not like:
+        return None, []
+    flat = torch.empty(sum(t.numel() for t in like), dtype=like[0].dtype, device=like[0].device)
+    views, off = [], 0
+    for t in like:
+        views.append(flat[off:off + t.numel()].view(t.shape))
+        off += t.numel()
+    return flat, views
+
+
+def _supports_out(ops) -> bool:
+    import inspect
+    try:
+        return "out" in inspect.signature(ops.backward).parameters
+    except (TypeError, ValueError):
+        return False
+
+
 class GlobalBatchCriticFn(torch.autograd.Function):
     """loss over the GLOBAL batch from this rank's row block.  Returns (loss[1], stats)."""
 
@@ -148,6 +177,8 @@ class GlobalBatchCriticFn(torch.autograd.Function):
         records = _all_gather_rows(record.reshape(1, -1), group)  # [G, 8], rank order
         loss, stats = ops.merge(records, world * br, estimator)
         ctx.ops, ctx.group, ctx.saved = ops, group, saved
+        ctx.param_like = [p.detach() for p in params]
+        ctx.y_all_like, ctx.x_shape = y_all, tuple(x.shape)
         ctx.save_for_backward(stats)
         ctx.mark_non_differentiable(stats)
         return loss, stats
@@ -156,10 +187,23 @@ class GlobalBatchCriticFn(torch.autograd.Function):
     def backward(ctx, grad_loss, _gstats):
         (stats,) = ctx.saved_tensors
         go = grad_loss.reshape(-1)[:1].to(torch.float32).contiguous()
-        gx, gy_partial, gparams = ctx.ops.backward(ctx.saved, stats, go)
+        params = ctx.param_like
+        flat, views = flat_views(params)
+        if flat is not None and _supports_out(ctx.ops):
+            y_all_like = ctx.y_all_like
+            gx = torch.empty(ctx.x_shape, dtype=y_all_like.dtype, device=y_all_like.device)
+            gy_partial = torch.empty_like(y_all_like)
+            ctx.ops.backward(ctx.saved, stats, go, out=(gx, gy_partial, views))
+            gparams = views
+        else:  # ops objects without preallocated outputs (the oracle-backed ones of the CPU tests)
+            gx, gy_partial, gparams = ctx.ops.backward(ctx.saved, stats, go)
+            if flat is not None:
+                for v, g in zip(views, gparams):
+                    v.copy_(g)
+                gparams = views
         gy = _reduce_scatter_rows(gy_partial, ctx.group)
-        for g in gparams:
-            dist.all_reduce(g, group=ctx.group)
+        if flat is not None:
+            dist.all_reduce(flat, group=ctx.group)  # one collective for all parameter gradients
         return (None, None, None, None, None, gx, gy, *gparams)
 
 
@@ -197,7 +241,7 @@ class GlobalBatchGraphStep:
     ``grad_params`` (overwritten by every step)."""
 
     def __init__(self, x, y, sid, params: Sequence[torch.Tensor], estimator: str = "infonce", precision: str = "bf16",
-                 critic: str = "bilinear", group=None, ops=None):
+                 critic: str = "bilinear", group=None, ops=None, capture: bool = True):
         from .mi_critics import _estimator_code, _precision_code
         self.group = group
         self.world = dist.get_world_size(group)
@@ -211,11 +255,22 @@ class GlobalBatchGraphStep:
                 raise ValueError("GlobalBatchGraphStep needs contiguous tensors (they are read in place)")
         br = x.shape[0]
         dev = x.device
+        on_gpu = dev.type == "cuda"
         self.y_all = torch.empty((self.world * br,) + tuple(y.shape[1:]), dtype=y.dtype, device=dev)
         self.sid_all = torch.empty(self.world * br, dtype=sid.dtype, device=dev)
-        self.records = torch.empty(self.world, _hip.RECORD_FLOATS, dtype=torch.float32, device=dev)
-        self.grad_out = torch.ones(1, dtype=torch.float32, device=dev)
+        self.records = torch.empty(self.world, _hip.RECORD_FLOATS, dtype=x.dtype if not on_gpu else torch.float32, device=dev)
+        self.grad_out = torch.ones(1, dtype=x.dtype if not on_gpu else torch.float32, device=dev)
+        # the parameter gradients of a step live in one flat buffer: ONE all-reduce per step
+        self.grad_flat, self.grad_params = flat_views(self.params)
+        self._out = None
+        if _supports_out(self.ops):
+            self.grad_x = torch.empty_like(self.x)
+            self.grad_y_partial = torch.empty_like(self.y_all)
+            self._out = (self.grad_x, self.grad_y_partial, self.grad_params)
+        self.graph_fwd = self.graph_bwd = None
         self._gather_inputs()
+        if not (capture and on_gpu):
+            return  # eager: the same calls issued one by one (the gloo tests on the CPU, `bench.py --graph off`)
         torch.cuda.synchronize()
         # warm-up on a side stream (module loading, attribute calls), then capture
         side = torch.cuda.Stream()
@@ -244,14 +299,34 @@ class GlobalBatchGraphStep:
 
     def _merge_backward(self):
         self.loss, self.stats = self.ops.merge(self.records, self.world * self.x.shape[0], self.est)
-        self.grad_x, self.grad_y_partial, self.grad_params = self.ops.backward(self.saved, self.stats, self.grad_out)
+        if self._out is not None:
+            self.ops.backward(self.saved, self.stats, self.grad_out, out=self._out)
+        else:
+            self.grad_x, self.grad_y_partial, gp = self.ops.backward(self.saved, self.stats, self.grad_out)
+            for v, g in zip(self.grad_params, gp):
+                v.copy_(g)
+
+    def _exchange_gradients(self):
+        self.grad_y = _reduce_scatter_rows(self.grad_y_partial, self.group)
+        if self.grad_flat is not None:
+            dist.all_reduce(self.grad_flat, group=self.group)
 
     def step(self):
+        """all-gather Y, ids | local forward | all-gather records | merge + local backward | reduce-scatter dY, ONE
+        all-reduce of the flat parameter-gradient buffer.  Five collectives per step, in this order on every rank."""
+        if self.graph_fwd is None:
+            return self.step_eager()
         self._gather_inputs()
         self.graph_fwd.replay()
         dist.all_gather_into_tensor(self.records, self.record.reshape(1, -1), group=self.group)
         self.graph_bwd.replay()
-        self.grad_y = _reduce_scatter_rows(self.grad_y_partial, self.group)
-        for g in self.grad_params:
-            dist.all_reduce(g, group=self.group)
+        self._exchange_gradients()
+        return self.loss
+
+    def step_eager(self):
+        self._gather_inputs()
+        self._forward()
+        dist.all_gather_into_tensor(self.records, self.record.reshape(1, -1).to(self.records.dtype), group=self.group)
+        self._merge_backward()
+        self._exchange_gradients()
         return self.loss

@@ -185,4 +185,6 @@ class _GraphedFn(torch.autograd.Function):
         step.grad_out.copy_(grad_loss.reshape(-1)[:1])
         step.backward()
         # clones: autograd may keep (or accumulate into) what it is handed, and the buffers are rewritten next step
-        return (None, step.grad_x.clone(), step.grad_y.clone(), *[g.clone() for g in step.grad_params])
+        grads = (None, step.grad_x.clone(), step.grad_y.clone(), *[g.clone() for g in step.grad_params])
+        step.grad_out.fill_(1.0)  # raw step() calls always differentiate 1 * loss
+        return grads

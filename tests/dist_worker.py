@@ -55,6 +55,73 @@ class OracleBilinearOps:
         return g @ y_all @ w.t(), g.t() @ t, [x.t() @ (g @ y_all)]
 
 
+class OracleAutogradOps(OracleBilinearOps):
+    """Any [b_rows, b] scorer through autograd (fp64): the concat-MLP critic of the reference and the bilinear one."""
+
+    def __init__(self, scorer):
+        self.scorer = scorer
+
+    def forward(self, x, y_all, params, sid_rows, sid_all, row_offset, estimator, precision, need_grad):
+        with torch.enable_grad():  # called from inside an autograd.Function.forward, where grad mode is off
+            leaves = [t.detach().clone().requires_grad_(True) for t in (x, y_all, *params)]
+            s = self.scorer(*leaves)
+        br, b = s.shape
+        diag = (torch.arange(br)[:, None] + row_offset) == torch.arange(b)[None, :]
+        neg = (~diag) & (sid_rows[:, None] != sid_all[None, :])
+        sd = s.detach()
+        m = sd[neg].max()
+        cnt = int(neg.sum())
+        rec = torch.tensor([float(m), float(torch.exp(sd[neg] - m).sum()), float(sd[diag].sum()), float(cnt & 0xFFFFFF),
+                            float(cnt >> 24), 0, 0, 0], dtype=x.dtype)
+        return rec, (leaves, s, diag, neg)
+
+    def backward(self, saved, stats, grad_out):
+        leaves, s, diag, neg = saved
+        lse, n_pos = stats[0], stats[1]
+        sd = s.detach()
+        g = (torch.where(neg, torch.exp(sd - lse), torch.zeros_like(sd)) - diag.to(sd.dtype) / n_pos) * grad_out.to(sd.dtype)
+        grads = torch.autograd.grad(s, leaves, g)
+        return grads[0], grads[1], list(grads[2:])
+
+
+def _concat_scorer(x, y_all, w1, b1, w2, b2, w3, b3):
+    from oracle import mi_oracle as orc
+    return orc.concat_scores_matrix(x, y_all, [w1, b1, w2, b2, w3.reshape(1, -1), b3])
+
+
+def run_concat(rank, world, port, b_local, d, estimator, out_dir, staged):
+    """The concat-MLP critic's exchange (six parameter gradients in ONE flat all-reduce), through the autograd wrapper
+    (staged = False) or through GlobalBatchGraphStep's eager call sequence (staged = True: the order of its five
+    collectives is what a hipGraph-replayed run issues too)."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from mutual_info_img_txt.distributed import GlobalBatchGraphStep, global_batch_mi_bound
+    from oracle import mi_oracle as orc
+    b = b_local * world
+    x, y, sid, params = orc.synthetic_case(b, d, d, h1=12, h2=8, salt=23, dup=True, dtype=torch.float64)
+    params[4] = params[4].reshape(-1)
+    from mutual_info_img_txt.utils import study_ids_to_tensor
+    codes = study_ids_to_tensor(sid)           # deterministic codes: every rank maps an id to the same integer
+    sl = slice(rank * b_local, (rank + 1) * b_local)
+    ops = OracleAutogradOps(_concat_scorer)
+    if staged:
+        st = GlobalBatchGraphStep(x[sl].contiguous(), y[sl].contiguous(), codes[sl].contiguous(), params, estimator, "f32",
+                                  critic="concat_mlp", group=dist.group.WORLD, ops=ops, capture=False)
+        loss = st.step()
+        out = {"loss": loss.detach().reshape(-1), "dx": st.grad_x, "dy": st.grad_y, "dparams": [g.clone() for g in st.grad_params]}
+    else:
+        xl = x[sl].clone().requires_grad_(True)
+        yl = y[sl].clone().requires_grad_(True)
+        pl = [p.clone().requires_grad_(True) for p in params]
+        loss = global_batch_mi_bound(xl, yl, codes[sl].contiguous(), pl, estimator, "f32", critic="concat_mlp",
+                                     group=dist.group.WORLD, ops=ops)
+        loss.sum().backward()
+        out = {"loss": loss.detach().reshape(-1), "dx": xl.grad, "dy": yl.grad, "dparams": [p.grad for p in pl]}
+    torch.save(out, os.path.join(out_dir, f"rank{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def run(rank, world, port, b_local, d, estimator, out_dir):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)

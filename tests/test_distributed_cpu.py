@@ -39,3 +39,26 @@ def test_global_batch_two_ranks_equals_single_process(tmp_path, estimator):
     # every rank holds bit-identical loss and parameter gradient (records merged in rank order, all-reduced grads)
     assert torch.equal(outs[0]["loss"], outs[1]["loss"])
     assert torch.equal(outs[0]["dw"], outs[1]["dw"])
+
+
+@pytest.mark.parametrize("staged", [False, True])
+def test_concat_exchange_two_ranks_equals_single_process(tmp_path, staged):
+    """The reference critic (concat-MLP) sharded over two ranks: its six parameter gradients travel in one flat
+    all-reduce; `staged` drives GlobalBatchGraphStep's call sequence instead of the autograd wrapper."""
+    world, b_local, d = 2, 5, 4
+    mp.spawn(dist_worker.run_concat, args=(world, _free_port(), b_local, d, "dv", str(tmp_path), staged), nprocs=world,
+             join=True)
+    b = world * b_local
+    x, y, sid, params = orc.synthetic_case(b, d, d, h1=12, h2=8, salt=23, dup=True, dtype=torch.float64)
+    ref = orc.concat_matrix_step(x, y, sid, params, "dv")
+    outs = [torch.load(os.path.join(tmp_path, f"rank{r}.pt"), weights_only=True) for r in range(world)]
+    for r, o in enumerate(outs):
+        sl = slice(r * b_local, (r + 1) * b_local)
+        np.testing.assert_allclose(o["loss"].numpy().reshape(-1), ref["loss"].numpy().reshape(-1), rtol=1e-9, atol=1e-9)
+        np.testing.assert_allclose(o["dx"].numpy(), ref["dx"][sl].numpy(), rtol=1e-8, atol=1e-12)
+        np.testing.assert_allclose(o["dy"].numpy(), ref["dy"][sl].numpy(), rtol=1e-8, atol=1e-12)
+        for got, want in zip(o["dparams"], ref["dparams"]):
+            np.testing.assert_allclose(got.numpy().reshape(-1), want.numpy().reshape(-1), rtol=1e-8, atol=1e-12)
+    for a, c in zip(outs[0]["dparams"], outs[1]["dparams"]):
+        assert torch.equal(a, c)
+    assert torch.equal(outs[0]["loss"], outs[1]["loss"])
