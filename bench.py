@@ -53,10 +53,10 @@ def parse_args():
     p.add_argument("--critic", default="bilinear", choices=["bilinear", "concat_mlp"])
     p.add_argument("--estimator", default="infonce", choices=["dv", "infonce"])
     p.add_argument("--precision", default="bf16", choices=["bf16", "f32"])
-    p.add_argument("--graph", default="on", choices=["auto", "on", "off"],
-                   help="replay the step from hipGraphs (default).  One GPU: forward and backward graphs of "
-                        "GraphedMiStep; N GPUs: the two compute sections are graphs and the RCCL collectives stay eager "
-                        "between them.  off: the same C-ABI calls issued one by one (host-bound for the bilinear step)")
+    p.add_argument("--graph", default="auto", choices=["auto", "on", "off"],
+                   help="on: replay the step from a hipGraph (one GPU: GraphedMiStep; N GPUs: the two compute sections "
+                        "are graphs, the RCCL collectives stay eager between them).  off: the same C-ABI calls issued one "
+                        "by one.  auto (default): one GPU times both during warm-up and keeps the faster; N GPUs = on")
     p.add_argument("--timed-iters", type=int, default=50, help="individually hipEvent-timed steps for the median (>= 50)")
     p.add_argument("--no-secondary", action="store_true")
     p.add_argument("--secondary-steps", type=int, default=5)
@@ -136,6 +136,8 @@ class Stepper:
         self.critic = make_critic(kind, d, d, 3, device)
         self.dist_mode = world > 1 or bool(os.environ.get("MI_BENCH_FORCE_DIST"))
         self.graph_used = bool(graph)
+        self.use_eager = not graph
+        self.launch_probe_ms = None
         if self.dist_mode:
             from mutual_info_img_txt.distributed import GlobalBatchGraphStep
             from mutual_info_img_txt.mi_critics import _concat_params
@@ -151,7 +153,28 @@ class Stepper:
             self.eager_obj = self.step_obj
 
     def step(self):
+        if self.use_eager:
+            return self.eager_step()
         return self.step_obj.step()
+
+    def choose_launch_mode(self, world):
+        """--graph auto: time a few steps of graph replay and of direct calls and keep the faster (a replay has ~10 us of
+        fixed cost; direct calls need a host that keeps ahead of the kernels).  Single GPU only."""
+        if self.dist_mode or not self.graph_used:
+            return
+        res = {}
+        for mode in ("graph", "eager"):
+            self.use_eager = mode == "eager"
+            for _ in range(5):
+                self.step()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(30):
+                self.step()
+            torch.cuda.synchronize()
+            res[mode] = (time.perf_counter() - t0) / 30 * 1e3
+        self.use_eager = res["eager"] < res["graph"]
+        self.launch_probe_ms = {k: round(v, 5) for k, v in res.items()}
 
     def eager_step(self):
         """The same C-ABI calls issued one by one (per-kernel event profiling needs real launches)."""
@@ -204,19 +227,11 @@ def timing_summary(stepper, iters):
     iters = max(50, int(iters))
     out = {"iters": iters}
     ms = sorted(event_timed(stepper.step, iters))
-    out["graph" if stepper.graph_used else "eager"] = {
+    out["launch_mode"] = "direct calls" if stepper.use_eager else "hipGraph replay"
+    out["launch_probe_ms"] = stepper.launch_probe_ms
+    out["timed_mode"] = {
         "median_ms": round(statistics.median(ms), 5), "p10_ms": round(ms[int(0.1 * (iters - 1))], 5),
         "p90_ms": round(ms[int(0.9 * (iters - 1))], 5)}
-    if stepper.graph_used and stepper.eager_obj is not None:
-        for _ in range(3):
-            stepper.eager_step()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(20):
-            stepper.eager_step()
-        torch.cuda.synchronize()
-        out["eager"] = {"mean_ms": round((time.perf_counter() - t0) / 20 * 1e3, 5),
-                        "note": "the same C-ABI calls issued one by one from Python: host-bound"}
     return out
 
 
@@ -359,6 +374,8 @@ def main():
 
     def run(kind, steps, warmup, precision=None, timed_iters=0):
         st = Stepper(kind, args, rank, world, device, group, precision=precision, graph=want_graph)
+        if args.graph == "auto":
+            st.choose_launch_mode(world)
         elapsed = timed_run(st, steps, warmup, world)
         timing = timing_summary(st, timed_iters) if timed_iters else None
         kernels = profile_kernels(st, args.profile_steps)
@@ -367,8 +384,8 @@ def main():
     st, elapsed, kernels, timing = run(args.critic, args.steps, args.warmup, timed_iters=args.timed_iters)
     ms = elapsed / args.steps * 1e3
     flops = algorithmic_flops(args.critic, b, d, d)
-    graph_mode = ("compute sections; collectives eager between them" if st.dist_mode else "forward graph + backward graph") \
-        if want_graph else "none"
+    graph_mode = "none (direct C-ABI calls)" if st.use_eager else \
+        ("compute sections; collectives eager between them" if st.dist_mode else "one graph: forward + backward")
     out = {
         "metric": "img-txt pairs/sec (MI critic fwd+bwd), global-batch InfoNCE",
         "value": round(b / (ms * 1e-3), 1),
@@ -386,7 +403,7 @@ def main():
                                f"{args.critic} critic fwd+bwd, B_global={b}, d={d}",
                    "global_batch": b, "embed_dim": d, "critic": args.critic, "estimator": args.estimator,
                    "parallelism": f"row-block sharding x{world}, RCCL all-gather of text embeddings" if world > 1 else "single GPU",
-                   "hip_graph": bool(want_graph), "graph_mode": graph_mode},
+                   "hip_graph": not st.use_eager, "graph_mode": graph_mode},
         "loss": st.loss(),
         "timing": timing,
         "step_algorithmic_tflops": round(flops / (ms * 1e-3) / 1e12, 2),
@@ -419,7 +436,7 @@ def main():
             out["secondary"] = {
                 "workload": f"{other} critic fwd+bwd, B_global={b}, d={d}" + (" (the reference's mi_discriminator)" if other == "concat_mlp" else ""),
                 "value": round(b / (ms3 * 1e-3), 1), "unit": "pairs/s", "ms_per_step": round(ms3, 4),
-                "steps": args.secondary_steps, "hip_graph": bool(want_graph), "loss": st3.loss(),
+                "steps": args.secondary_steps, "hip_graph": not st3.use_eager, "loss": st3.loss(),
                 "step_algorithmic_tflops": round(fl3 / (ms3 * 1e-3) / 1e12, 2),
                 "step_frac_of_peak": round(fl3 / (ms3 * 1e-3) / 1e12 / (PEAK_TFLOPS[args.precision] * world), 5),
                 "roofline": roofline_of(k3, br, b, d, args.precision),

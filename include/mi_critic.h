@@ -11,6 +11,7 @@
  *   mi_concat_mlp_*       <- the call site mutual_info_img_txt/main_utils.py:220-226:
  *                            create_mi_pairs -> mi_discriminator (make_mlp(1536,[1024,512]), model.py:18-32,
  *                            instantiated main_utils.py:77) -> mi_critic -> loss.backward()
+ *   mi_separable_*        <- same call site with the separable critic S = (X Wg)(Y Wh)^T (BASELINE.json configs[1])
  *   mi_bilinear_*         <- same call site with the bilinear critic S = (X W) Y^T named by BASELINE.json
  *                            (an extension: the reference has no bilinear critic; the bound, the masking and the
  *                            pair semantics applied to its scores are the reference's)
@@ -27,7 +28,10 @@
  *     query sizes with the *_workspace_bytes functions
  *   - return value: 0 on success, negative MI_E* code on failure; mi_last_error() describes the last failure
  *     on the calling thread.  No C++ exception crosses this boundary.
- *   - re-entrant, no global state; forward and backward may be called from different host threads
+ *   - re-entrant: forward and backward may be called from different host threads (autograd does).  Process-wide state is
+ *     limited to (a) per-device caches of kernel attributes (atomic, raised under a mutex) and (b) the optional
+ *     profiling hook mi_profile_begin/end, which is NOT thread-safe (single-threaded benchmarking only).  The library
+ *     never sets the device: the caller makes the tensors' device current (the Python binding does).
  *
  * estimator: MI_DV = 0 (loss = LSE(neg) - log N_neg - mean(pos)), MI_INFONCE = 1 (no log N_neg term).
  * precision: MI_PREC_F32 = 0 (fp32-input MFMA, exact fp32 products, parity mode),
@@ -136,6 +140,23 @@ int mi_bilinear_bwd(const float* x, const float* y, const float* w, const int64_
                     int64_t d_txt, int precision, const mi_stats* stats, const float* grad_out, float* grad_x,
                     float* grad_y, float* grad_w, void* workspace, size_t workspace_bytes,
                     int workspace_from_forward, void* stream);
+
+/* ---- fused separable critic: S = (X Wg)(Y Wh)^T, bound, all gradients ------------------------------- */
+/* BASELINE.json configs[1] (an extension: the reference has no separable critic; bound, masking and pair semantics are
+ * the reference's).  X [b_rows, d_img], Y [b, d_txt], Wg [d_img, d_proj], Wh [d_txt, d_proj].  The projections run on
+ * this library's MFMA kernels (no library GEMM).  Sharding arguments as for mi_bilinear_*. */
+size_t mi_separable_workspace_bytes(int64_t b_rows, int64_t b, int64_t d_img, int64_t d_txt, int64_t d_proj,
+                                    int precision);
+int mi_separable_fwd(const float* x, const float* y, const float* wg, const float* wh, const int64_t* sid_rows,
+                     const int64_t* sid_cols, int64_t b_rows, int64_t b, int64_t row_offset, int64_t d_img,
+                     int64_t d_txt, int64_t d_proj, int estimator, int precision, int need_grad, float* loss_out,
+                     mi_stats* stats, float* partials_out, void* workspace, size_t workspace_bytes, void* stream);
+/* grad_y [b, d_txt] is the partial over this row block; grad_wg / grad_wh are this row block's contributions. */
+int mi_separable_bwd(const float* x, const float* y, const float* wg, const float* wh, const int64_t* sid_rows,
+                     const int64_t* sid_cols, int64_t b_rows, int64_t b, int64_t row_offset, int64_t d_img,
+                     int64_t d_txt, int64_t d_proj, int precision, const mi_stats* stats, const float* grad_out,
+                     float* grad_x, float* grad_y, float* grad_wg, float* grad_wh, void* workspace,
+                     size_t workspace_bytes, int workspace_from_forward, void* stream);
 
 /* ---- fused concat-MLP critic (the reference's mi_discriminator) ------------------------------------ */
 /* params in PyTorch [out,in] layout: w1 [h1, d_img+d_txt], b1 [h1], w2 [h2, h1], b2 [h2], w3 [h2], b3 [1]. */

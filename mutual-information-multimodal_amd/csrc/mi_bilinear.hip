@@ -404,6 +404,287 @@ int mi_bilinear_bwd(const float* x, const float* y, const float* w, const int64_
 
 }  // extern "C"
 
+// ================================================================================================ separable critic
+// S = (X Wg)(Y Wh)^T  (BASELINE.json configs[1]; an extension: no reference code, oracle-pinned only).  Projections,
+// the fused B x B stage and every gradient are this library's kernels:
+//   forward : prep X, Y, Wg, Wh -> A = X Wg | C = Y Wh (one two-problem launch; bf16 row-major + fragment-major copies)
+//             -> fused kernel (problem 0: A rows x C rows, problem 1: C rows x A rows) -> statistics
+//   backward: slab reduce -> dA, dC (bf16, both orientations) -> {dWg = X^T dA | dX = dA Wg^T}, {dWh = Y^T dC | dY = dC Wh^T}
+// Other shapes and the fp32 parity mode run on the generic strided-operand kernels (mi_gemm.h).
+namespace mi {
+
+struct SeparablePlan {
+  bool fast;
+  FlashPlan fl;
+  bf16_t *xb, *xtb, *yb, *ytb, *gb, *gtb, *hb, *htb;   // X, Y, Wg, Wh as bf16, row-major and transposed
+  bf16_t *ab, *afb, *cb, *cfb;                          // projections, row-major and fragment-major
+  bf16_t *dab, *datb, *dcb, *dctb;                      // their gradients, both orientations
+  float *slab[2];
+  Partial* rec[2];
+  unsigned char* dup[2];
+  float *wg_slab, *wh_slab;
+  int wg_splits, wh_splits;
+  int64_t wg_kchunk, wh_kchunk;
+  // generic path
+  float *a32, *c32, *da32, *dc32;
+  void* g;
+  Partial* partials;
+  int64_t n_partials;
+  size_t bytes;
+};
+
+static void split_plan(int64_t rows, int64_t m, int64_t n, int& splits, int64_t& kchunk) {
+  const int64_t tiles = ((m + kTile - 1) / kTile) * ((n + kTile - 1) / kTile);
+  int64_t sp = (128 + tiles - 1) / tiles;
+  kchunk = (rows + sp - 1) / sp;
+  kchunk = (kchunk + kG2KT - 1) / kG2KT * kG2KT;
+  splits = (int)((rows + kchunk - 1) / kchunk);
+}
+
+static SeparablePlan plan_separable(Workspace& ws, int64_t br, int64_t b, int64_t dx, int64_t dy, int64_t k,
+                                    int precision) {
+  SeparablePlan p{};
+  p.fl = FlashPlan{};
+  if (precision == MI_PREC_BF16 && dx % 8 == 0 && dy % 8 == 0 && k % 64 == 0) p.fl = flash_plan(br, b, k);
+  p.fast = p.fl.ok;
+  if (p.fast) {
+    p.xb = ws.take<bf16_t>(br * dx);
+    p.xtb = ws.take<bf16_t>(br * dx);
+    p.yb = ws.take<bf16_t>(b * dy);
+    p.ytb = ws.take<bf16_t>(b * dy);
+    p.gb = ws.take<bf16_t>(dx * k);
+    p.gtb = ws.take<bf16_t>(dx * k);
+    p.hb = ws.take<bf16_t>(dy * k);
+    p.htb = ws.take<bf16_t>(dy * k);
+    p.ab = ws.take<bf16_t>(br * k);
+    p.afb = ws.take<bf16_t>(br * k);
+    p.cb = ws.take<bf16_t>(b * k);
+    p.cfb = ws.take<bf16_t>(b * k);
+    p.dab = ws.take<bf16_t>(br * k);
+    p.datb = ws.take<bf16_t>(br * k);
+    p.dcb = ws.take<bf16_t>(b * k);
+    p.dctb = ws.take<bf16_t>(b * k);
+    for (int q = 0; q < 2; ++q) {
+      p.rec[q] = ws.take<Partial>(p.fl.n_rec[q]);
+      p.slab[q] = ws.take<float>(p.fl.slab_floats[q]);
+      p.dup[q] = ws.take<unsigned char>((br / 32) * (b / 32));
+    }
+    split_plan(br, dx, k, p.wg_splits, p.wg_kchunk);
+    split_plan(b, dy, k, p.wh_splits, p.wh_kchunk);
+    p.wg_slab = ws.take<float>((int64_t)p.wg_splits * dx * k);
+    p.wh_slab = ws.take<float>((int64_t)p.wh_splits * dy * k);
+  } else {
+    p.a32 = ws.take<float>(br * k);
+    p.c32 = ws.take<float>(b * k);
+    p.da32 = ws.take<float>(br * k);
+    p.dc32 = ws.take<float>(b * k);
+    p.n_partials = ((b + kTile - 1) / kTile) * ((br + kTile - 1) / kTile);
+    p.partials = ws.take<Partial>(p.n_partials);
+    if (precision == MI_PREC_BF16) p.g = ws.take<bf16_t>(br * b);
+    else p.g = ws.take<float>(br * b);
+  }
+  p.bytes = ws.off;
+  return p;
+}
+
+static int separable_prep_project(const float* x, const float* y, const float* wg, const float* wh,
+                                  const int64_t* sid_rows, const int64_t* sid_cols, int64_t br, int64_t b, int64_t dx,
+                                  int64_t dy, int64_t k, const SeparablePlan& p, hipStream_t st) {
+  CvtJobs jobs{};
+  jobs.j[0] = CvtJob{x, br, dx, p.xb, p.xtb, 0, 0, nullptr};
+  jobs.j[1] = CvtJob{y, b, dy, p.yb, p.ytb, 0, 0, nullptr};
+  jobs.j[2] = CvtJob{wg, dx, k, p.gb, p.gtb, 0, 0, nullptr};
+  jobs.j[3] = CvtJob{wh, dy, k, p.hb, p.htb, 0, 0, nullptr};
+  jobs.dup = DupFlagJob{sid_rows, sid_cols, (int)(br / 32), (int)(b / 32), p.dup[0], p.dup[1]};
+  int rc = launch_cvt_transpose3(jobs, st, "separable prep X Y Wg Wh");
+  if (rc) return rc;
+  // A[i, c] = sum_a X[i, a] Wg[a, c] (A operand Xb [br][dx], B operand Wg^T [k][dx]);  C likewise from Y, Wh
+  GemmBf16Args two{};
+  two.p[0] = GemmBf16Problem{p.xb, dx, p.gtb, dx, br, k, dx};
+  two.p[1] = GemmBf16Problem{p.yb, dy, p.htb, dy, b, k, dy};
+  two.n_problems = 2;
+  two.k_chunk = dx > dy ? dx : dy;
+  EpiStoreMulti e{};
+  e.out[0] = EpiOut{nullptr, 0, 0, p.ab, k, nullptr, 0, p.afb};
+  e.out[1] = EpiOut{nullptr, 0, 0, p.cb, k, nullptr, 0, p.cfb};
+  return launch_gemm_bf16(two, 1, e, st, "separable A = X Wg | C = Y Wh");
+}
+
+static int separable_flash(const int64_t* sid_rows, const int64_t* sid_cols, int64_t br, int64_t b, int64_t row_offset,
+                           int64_t k, bool grad, const SeparablePlan& p, hipStream_t st) {
+  FlashArgs a{};
+  a.p[0] = FlashProblem{p.afb, p.cb, sid_rows, sid_cols, br, b, row_offset, p.fl.n_rb[0], p.fl.n_split[0],
+                        p.fl.tiles_per_split[0], p.dup[0], p.slab[0], p.rec[0]};
+  a.p[1] = FlashProblem{p.cfb, p.ab, sid_cols, sid_rows, b, br, -row_offset, p.fl.n_rb[1], p.fl.n_split[1],
+                        p.fl.tiles_per_split[1], p.dup[1], p.slab[1], p.rec[1]};
+  a.n_problems = grad ? 2 : 1;
+  return launch_flash(a, k, grad, st, grad ? "separable fused S | P C | P^T A" : "separable fused S + LSE");
+}
+
+static int check_separable(const char* fn, int64_t br, int64_t b, int64_t row_offset, int64_t dx, int64_t dy, int64_t k,
+                           int precision) {
+  int rc = check_common(fn, br, b, row_offset, dx, dy, precision);
+  if (rc) return rc;
+  MI_CHECK_ARG(k >= 1, "%s: projection width must be >= 1", fn);
+  return MI_OK;
+}
+
+}  // namespace mi
+
+extern "C" {
+
+size_t mi_separable_workspace_bytes(int64_t b_rows, int64_t b, int64_t d_img, int64_t d_txt, int64_t d_proj,
+                                    int precision) {
+  Workspace ws(nullptr, 0);
+  return plan_separable(ws, b_rows, b, d_img, d_txt, d_proj, precision).bytes + 256;
+}
+
+int mi_separable_fwd(const float* x, const float* y, const float* wg, const float* wh, const int64_t* sid_rows,
+                     const int64_t* sid_cols, int64_t b_rows, int64_t b, int64_t row_offset, int64_t d_img,
+                     int64_t d_txt, int64_t d_proj, int estimator, int precision, int need_grad, float* loss_out,
+                     mi_stats* stats, float* partials_out, void* workspace, size_t workspace_bytes, void* stream) {
+  MI_CHECK_ARG(x && y && wg && wh && sid_rows && sid_cols && stats && workspace, "mi_separable_fwd: null pointer");
+  int rc = check_separable("mi_separable_fwd", b_rows, b, row_offset, d_img, d_txt, d_proj, precision);
+  if (rc) return rc;
+  MI_CHECK_ARG(estimator == MI_DV || estimator == MI_INFONCE, "mi_separable_fwd: unknown estimator %d", estimator);
+  Workspace ws(workspace, workspace_bytes);
+  SeparablePlan p = plan_separable(ws, b_rows, b, d_img, d_txt, d_proj, precision);
+  if (!ws.ok()) {
+    set_error("mi_separable_fwd: workspace too small (%zu < %zu)", workspace_bytes, ws.off);
+    return MI_EWORKSPACE;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  if (p.fast) {
+    rc = separable_prep_project(x, y, wg, wh, sid_rows, sid_cols, b_rows, b, d_img, d_txt, d_proj, p, st);
+    if (rc) return rc;
+    rc = separable_flash(sid_rows, sid_cols, b_rows, b, row_offset, d_proj, need_grad != 0, p, st);
+    if (rc) return rc;
+    return launch_finalize(p.rec[0], p.fl.n_rec[0], b, estimator, loss_out, stats, partials_out, st);
+  }
+  // generic: projections on the strided-operand kernels (exact fp32 products in the parity mode), then the S = A C^T
+  // score + LSE kernel of the bilinear path's generic form
+  const bool f32 = precision == MI_PREC_F32;
+  auto project = [&](const float* in, const float* w, int64_t rows, int64_t d, float* out, const char* what) {
+    return f32 ? launch_gemm<float>(make_operand(in, d, 1), make_operand(w, 1, d_proj), rows, d_proj, d,
+                                    EpiStore{out, d_proj, nullptr, 1.0f, 0}, st, what)
+               : launch_gemm<bf16_t>(make_operand(in, d, 1), make_operand(w, 1, d_proj), rows, d_proj, d,
+                                     EpiStore{out, d_proj, nullptr, 1.0f, 0}, st, what);
+  };
+  rc = project(x, wg, b_rows, d_img, p.a32, "separable A = X Wg (generic)");
+  if (rc) return rc;
+  rc = project(y, wh, b, d_txt, p.c32, "separable C = Y Wh (generic)");
+  if (rc) return rc;
+  EpiScoreLse epi{sid_rows, sid_cols, row_offset, nullptr, p.partials};
+  rc = f32 ? launch_gemm<float>(make_operand((const float*)p.a32, d_proj, 1), make_operand((const float*)p.c32, d_proj, 1),
+                                b_rows, b, d_proj, epi, st, "separable score+LSE (generic)")
+           : launch_gemm<bf16_t>(make_operand((const float*)p.a32, d_proj, 1), make_operand((const float*)p.c32, d_proj, 1),
+                                 b_rows, b, d_proj, epi, st, "separable score+LSE (generic)");
+  if (rc) return rc;
+  return launch_finalize(p.partials, p.n_partials, b, estimator, loss_out, stats, partials_out, st);
+}
+
+int mi_separable_bwd(const float* x, const float* y, const float* wg, const float* wh, const int64_t* sid_rows,
+                     const int64_t* sid_cols, int64_t b_rows, int64_t b, int64_t row_offset, int64_t d_img,
+                     int64_t d_txt, int64_t d_proj, int precision, const mi_stats* stats, const float* grad_out,
+                     float* grad_x, float* grad_y, float* grad_wg, float* grad_wh, void* workspace,
+                     size_t workspace_bytes, int workspace_from_forward, void* stream) {
+  MI_CHECK_ARG(x && y && wg && wh && sid_rows && sid_cols && stats && grad_x && grad_y && grad_wg && grad_wh && workspace,
+               "mi_separable_bwd: null pointer");
+  int rc = check_separable("mi_separable_bwd", b_rows, b, row_offset, d_img, d_txt, d_proj, precision);
+  if (rc) return rc;
+  Workspace ws(workspace, workspace_bytes);
+  SeparablePlan p = plan_separable(ws, b_rows, b, d_img, d_txt, d_proj, precision);
+  if (!ws.ok()) {
+    set_error("mi_separable_bwd: workspace too small (%zu < %zu)", workspace_bytes, ws.off);
+    return MI_EWORKSPACE;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t br = b_rows, k = d_proj;
+  if (p.fast) {
+    if (!workspace_from_forward) {
+      rc = separable_prep_project(x, y, wg, wh, sid_rows, sid_cols, br, b, d_img, d_txt, k, p, st);
+      if (rc) return rc;
+      rc = separable_flash(sid_rows, sid_cols, br, b, row_offset, k, true, p, st);
+      if (rc) return rc;
+    }
+    FlashReduceArgs ra{};
+    ra.j[0] = FlashReduceJob{p.slab[0], p.rec[0], p.fl.n_split[0], p.fl.n_rb[0], br, p.cb, b, row_offset, nullptr, p.dab,
+                             p.datb};
+    ra.j[1] = FlashReduceJob{p.slab[1], p.rec[1], p.fl.n_split[1], p.fl.n_rb[1], b, p.ab, br, -row_offset, nullptr, p.dcb,
+                             p.dctb};
+    ra.stats = stats;
+    ra.grad_out = grad_out;
+    rc = launch_flash_reduce(ra, 2, k, st, "separable dA, dC from the fused sums");
+    if (rc) return rc;
+    // per modality: dW[a, c] = sum_i X[i, a] dA[i, c] (split over i into slabs) | dX[i, a] = sum_c dA[i, c] W[a, c]
+    auto pair = [&](const bf16_t* xt, const bf16_t* dat, const bf16_t* da, const bf16_t* wb, int64_t rows, int64_t d,
+                    float* slab, int splits, int64_t kchunk, float* gx, float* gw, const char* what) {
+      GemmBf16Args g{};
+      g.p[0] = GemmBf16Problem{xt, rows, dat, rows, d, k, rows};
+      g.p[1] = GemmBf16Problem{da, k, wb, k, rows, d, k};
+      g.n_problems = 2;
+      EpiStoreMulti e{};
+      e.out[0] = EpiOut{slab, k, d * k, nullptr, 0, nullptr, 0};
+      e.out[1] = EpiOut{gx, d, 0, nullptr, 0, nullptr, 0};
+      const int sp[2] = {splits, 1};
+      const int64_t ch[2] = {kchunk, k};
+      int r = launch_gemm_bf16_flat(g, sp, ch, e, st, what);
+      if (r == MI_EINVAL) {
+        EpiStoreMulti e1{};
+        e1.out[0] = e.out[0];
+        r = launch_gemm_bf16(one_problem(xt, rows, dat, rows, d, k, rows, kchunk), splits, e1, st, what);
+        if (r) return r;
+        e1.out[0] = e.out[1];
+        r = launch_gemm_bf16(one_problem(da, k, wb, k, rows, d, k), 1, e1, st, what);
+      }
+      if (r) return r;
+      return launch_slab_reduce_ld(slab, splits, d, k, gw, k, st, "slab_reduce_ld_kernel");
+    };
+    rc = pair(p.xtb, p.datb, p.dab, p.gb, br, d_img, p.wg_slab, p.wg_splits, p.wg_kchunk, grad_x, grad_wg,
+              "separable dWg = X^T dA | dX = dA Wg^T");
+    if (rc) return rc;
+    return pair(p.ytb, p.dctb, p.dcb, p.hb, b, d_txt, p.wh_slab, p.wh_splits, p.wh_kchunk, grad_y, grad_wh,
+                "separable dWh = Y^T dC | dY = dC Wh^T");
+  }
+  // generic path: recompute the projections (cheap), G from recomputed scores, then six strided-operand products
+  const bool f32 = precision == MI_PREC_F32;
+#define MI_SEP_GEMM(A, B, M, N, K, OUT, LD, WHAT)                                                                    \
+  do {                                                                                                               \
+    rc = f32 ? launch_gemm<float>(A, B, M, N, K, EpiStore{OUT, LD, nullptr, 1.0f, 0}, st, WHAT)                       \
+             : launch_gemm<bf16_t>(A, B, M, N, K, EpiStore{OUT, LD, nullptr, 1.0f, 0}, st, WHAT);                     \
+    if (rc) return rc;                                                                                               \
+  } while (0)
+  MI_SEP_GEMM(make_operand(x, d_img, 1), make_operand(wg, 1, k), br, k, d_img, p.a32, k, "separable A = X Wg (generic, bwd)");
+  MI_SEP_GEMM(make_operand(y, d_txt, 1), make_operand(wh, 1, k), b, k, d_txt, p.c32, k, "separable C = Y Wh (generic, bwd)");
+  const float* a = p.a32;
+  const float* c = p.c32;
+  if (f32) {
+    float* g = (float*)p.g;
+    rc = launch_gemm<float>(make_operand(a, k, 1), make_operand(c, k, 1), br, b, k,
+                            EpiGradScore<float>{sid_rows, sid_cols, row_offset, stats, grad_out, g}, st, "separable G (generic)");
+    if (rc) return rc;
+    MI_SEP_GEMM(make_operand((const float*)g, b, 1), make_operand(c, 1, k), br, k, b, p.da32, k, "separable dA = G C (generic)");
+    MI_SEP_GEMM(make_operand((const float*)g, 1, b), make_operand(a, 1, k), b, k, br, p.dc32, k, "separable dC = G^T A (generic)");
+  } else {
+    bf16_t* g = (bf16_t*)p.g;
+    rc = launch_gemm<bf16_t>(make_operand(a, k, 1), make_operand(c, k, 1), br, b, k,
+                             EpiGradScore<bf16_t>{sid_rows, sid_cols, row_offset, stats, grad_out, g}, st, "separable G (generic)");
+    if (rc) return rc;
+    MI_SEP_GEMM(make_operand((const bf16_t*)g, b, 1), make_operand(c, 1, k), br, k, b, p.da32, k, "separable dA = G C (generic)");
+    MI_SEP_GEMM(make_operand((const bf16_t*)g, 1, b), make_operand(a, 1, k), b, k, br, p.dc32, k, "separable dC = G^T A (generic)");
+  }
+  const float* da = p.da32;
+  const float* dc = p.dc32;
+  MI_SEP_GEMM(make_operand(da, k, 1), make_operand(wg, k, 1), br, d_img, k, grad_x, d_img, "separable dX = dA Wg^T (generic)");
+  MI_SEP_GEMM(make_operand(x, 1, d_img), make_operand(da, 1, k), d_img, k, br, grad_wg, k, "separable dWg = X^T dA (generic)");
+  MI_SEP_GEMM(make_operand(dc, k, 1), make_operand(wh, k, 1), b, d_txt, k, grad_y, d_txt, "separable dY = dC Wh^T (generic)");
+  MI_SEP_GEMM(make_operand(y, 1, d_txt), make_operand(dc, 1, k), d_txt, k, b, grad_wh, k, "separable dWh = Y^T dC (generic)");
+#undef MI_SEP_GEMM
+  return MI_OK;
+}
+
+}  // extern "C"
+
 #ifdef MI_STAMPS
 // diagnostic build only: where the stamped kernels of this translation unit write their s_memtime values
 extern "C" int mi_debug_set_stamps(void* buf) {

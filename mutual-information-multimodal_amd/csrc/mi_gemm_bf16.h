@@ -1195,8 +1195,8 @@ struct DupFlagJob {
   unsigned char* flag_t;   // [nb][na]
 };
 struct CvtJobs {
-  CvtJob j[3];
-  DupFlagJob dup;
+  CvtJob j[4];     // blockIdx.z = 0..3 (unused jobs have R == 0)
+  DupFlagJob dup;  // blockIdx.z = 4
 };
 
 // flag[a][b] = 1 iff some image row of block a and some text row of block b share a study id.  One call handles the 64
@@ -1232,7 +1232,7 @@ __device__ __forceinline__ void dup_flags_block(const DupFlagJob& J, int a, int 
 static __global__ __launch_bounds__(256) void cvt_transpose3_kernel(CvtJobs jobs) {
   kernarg_prefetch<(int)sizeof(CvtJobs)>();
   __shared__ float tile[64][65];
-  if (blockIdx.z == 3) {  // the equal-id flags ride along: (row block, 64 column blocks) pairs over this slice's blocks
+  if (blockIdx.z == 4) {  // the equal-id flags ride along: (row block, 64 column blocks) pairs over this slice's blocks
     const DupFlagJob& D = jobs.dup;
     const int chunks = (D.nb + 63) / 64, total = D.na * chunks;
     for (int w = (int)(blockIdx.y * gridDim.x + blockIdx.x); w < total; w += (int)(gridDim.x * gridDim.y)) {
@@ -1302,24 +1302,24 @@ static __global__ __launch_bounds__(256) void cvt_transpose3_generic_kernel(CvtJ
 static inline int launch_cvt_transpose3(const CvtJobs& jobs, hipStream_t st, const char* what) {
   int64_t rmax = 0, cmax = 0;
   bool vec = true;
-  for (int q = 0; q < 3; ++q) {
+  for (int q = 0; q < 4; ++q) {
     const CvtJob& J = jobs.j[q];
     if (J.R > rmax) rmax = J.R;
     if (J.C > cmax) cmax = J.C;
     vec = vec && J.R % 4 == 0 && J.C % 4 == 0 && (uintptr_t)J.in % 16 == 0 && (uintptr_t)J.out_rm % 8 == 0 &&
           (uintptr_t)J.out_t % 8 == 0 && J.slab_stride % 4 == 0 && (!J.out_frag || (J.R % 32 == 0 && J.C % 16 == 0));
   }
-  if (!vec && (jobs.dup.na > 0 || jobs.j[0].out_frag || jobs.j[1].out_frag || jobs.j[2].out_frag)) {
+  if (!vec && (jobs.dup.na > 0 || jobs.j[0].out_frag || jobs.j[1].out_frag || jobs.j[2].out_frag || jobs.j[3].out_frag)) {
     set_error("%s: fragment-major outputs / id flags need the vectorised conversion kernel (aligned, multiples of 4)", what);
     return MI_ESHAPE;
   }
   {
     ProfScope prof_(what, st);
     if (vec) {
-      dim3 grid((unsigned)((cmax + 63) / 64), (unsigned)((rmax + 63) / 64), jobs.dup.na > 0 ? 4 : 3);
+      dim3 grid((unsigned)((cmax + 63) / 64), (unsigned)((rmax + 63) / 64), jobs.dup.na > 0 ? 5 : 4);
       hipLaunchKernelGGL(cvt_transpose3_kernel, grid, dim3(256), 0, st, jobs);
     } else {
-      dim3 grid((unsigned)((cmax + 31) / 32), (unsigned)((rmax + 31) / 32), 3);
+      dim3 grid((unsigned)((cmax + 31) / 32), (unsigned)((rmax + 31) / 32), 4);
       hipLaunchKernelGGL(cvt_transpose3_generic_kernel, grid, dim3(256), 0, st, jobs);
     }
   }

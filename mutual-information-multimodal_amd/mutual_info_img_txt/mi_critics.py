@@ -23,7 +23,7 @@ from . import _hip
 from ._hip import ESTIMATORS, PRECISIONS
 
 __all__ = ["dv_bound_loss", "infonce_bound_loss", "matrix_bound_loss", "fused_mi_bound", "study_id_codes",
-           "BilinearCriticFn", "ConcatMlpCriticFn"]
+           "BilinearCriticFn", "SeparableCriticFn", "ConcatMlpCriticFn"]
 
 
 # ----------------------------------------------------------------------------------------------------------
@@ -200,6 +200,46 @@ class BilinearCriticFn(torch.autograd.Function):
         return gx, gy, gw, None, None, None, None
 
 
+class SeparableCriticFn(torch.autograd.Function):
+    """loss = bound(S), S = (X Wg)(Y Wh)^T with study-id masking; projections, fused B x B stage and all gradients by
+    the HIP library (BASELINE.json configs[1])."""
+
+    @staticmethod
+    def forward(ctx, x, y, wg, wh, sid, estimator: int, precision: int):
+        lib = _hip.load()
+        x, y = _hip.f32c(x, "embedding_img"), _hip.f32c(y, "embedding_txt")
+        wg, wh = _hip.f32c(wg, "image projection"), _hip.f32c(wh, "text projection")
+        b, dx = x.shape
+        dy, k = y.shape[1], wg.shape[1]
+        if wg.shape[0] != dx or wh.shape != (dy, k):
+            raise ValueError("projection shapes must be [d_img, d_proj] and [d_txt, d_proj]")
+        dev = x.device
+        ws = _hip.workspace(lib.mi_separable_workspace_bytes(b, b, dx, dy, k, precision), dev)
+        stats = _hip.new_stats(dev)
+        loss = torch.empty(1, dtype=torch.float32, device=dev)
+        record = torch.empty(_hip.RECORD_FLOATS, dtype=torch.float32, device=dev)
+        need_grad = 1 if any(ctx.needs_input_grad[:4]) else 0
+        _hip.call("mi_separable_fwd", dev, x.data_ptr(), y.data_ptr(), wg.data_ptr(), wh.data_ptr(), sid.data_ptr(),
+                  sid.data_ptr(), b, b, 0, dx, dy, k, estimator, precision, need_grad, loss.data_ptr(), stats.data_ptr(),
+                  record.data_ptr(), ws.data_ptr(), ws.numel())
+        ctx.save_for_backward(x, y, wg, wh, sid, stats, ws)
+        ctx.precision = precision
+        ctx.mark_non_differentiable(stats)
+        return loss, stats
+
+    @staticmethod
+    def backward(ctx, grad_loss, _gs):
+        x, y, wg, wh, sid, stats, ws = ctx.saved_tensors
+        b, dx = x.shape
+        dy, k = y.shape[1], wg.shape[1]
+        go = _grad_scalar(grad_loss)
+        gx, gy, gg, gh = (torch.empty_like(t) for t in (x, y, wg, wh))
+        _hip.call("mi_separable_bwd", x.device, x.data_ptr(), y.data_ptr(), wg.data_ptr(), wh.data_ptr(), sid.data_ptr(),
+                  sid.data_ptr(), b, b, 0, dx, dy, k, ctx.precision, stats.data_ptr(), go.data_ptr(), gx.data_ptr(),
+                  gy.data_ptr(), gg.data_ptr(), gh.data_ptr(), ws.data_ptr(), ws.numel(), 1)
+        return gx, gy, gg, gh, None, None, None
+
+
 class ConcatMlpCriticFn(torch.autograd.Function):
     """loss = bound(S), S[i,j] = MLP([x_i ; y_j]) with the reference critic make_mlp(d,[h1,h2]) (model.py:18-32)."""
 
@@ -292,9 +332,13 @@ def fused_mi_bound(embedding_img: torch.Tensor, embedding_txt: torch.Tensor, stu
         loss, stats, scores = BilinearCriticFn.apply(embedding_img, embedding_txt, critic.weight, sid, code, prec,
                                                      bool(return_scores))
     elif isinstance(critic, _model.SeparableCritic):
-        a = critic.project_img(embedding_img)
-        c = critic.project_txt(embedding_txt)
-        loss, stats, scores = BilinearCriticFn.apply(a, c, None, sid, code, prec, bool(return_scores))
+        if return_scores:  # per-pair scores are a diagnostic output: eager projections + the bilinear form with W = None
+            a = critic.project_img(embedding_img)
+            c = critic.project_txt(embedding_txt)
+            loss, stats, scores = BilinearCriticFn.apply(a, c, None, sid, code, prec, True)
+        else:
+            loss, stats = SeparableCriticFn.apply(embedding_img, embedding_txt, critic.wg, critic.wh, sid, code, prec)
+            scores = None
     else:
         w1, b1, w2, b2, w3, b3 = _concat_params(critic)
         if w1.shape[1] != embedding_img.shape[1] + embedding_txt.shape[1]:

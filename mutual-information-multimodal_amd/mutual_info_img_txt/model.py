@@ -43,8 +43,9 @@ class BilinearCritic(nn.Module):
 
 
 class SeparableCritic(nn.Module):
-    """S[i,j] = (x_i Wg) . (y_j Wh)  (extension; BASELINE.json config 2).  The projections are ordinary torch matmuls
-    (plain library GEMMs); the B x B contraction, bound and backward are the fused HIP path."""
+    """S[i,j] = (x_i Wg) . (y_j Wh)  (extension; BASELINE.json configs[1]).  Through ``mi_critics.fused_mi_bound`` the
+    projections, the B x B contraction, the bound and every gradient run on the HIP library (``mi_separable_fwd/bwd``);
+    ``forward`` / ``project_*`` below are the eager torch form, kept for reference-style use."""
 
     def __init__(self, d_img: int, d_txt: int, d_proj: int):
         super().__init__()

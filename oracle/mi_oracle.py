@@ -246,6 +246,25 @@ def bilinear_step_rounded(x, y, w, study_id: Sequence, estimator: str, row_block
     return {"scores": s, "loss": loss, "dx": dt @ wb.t(), "dy": dy, "dw": xb[rows].t() @ dt, "dt": dt}
 
 
+def separable_step_rounded(x, y, wg, wh, study_id: Sequence, estimator: str):
+    """Extension (no reference code).  fp64 forward + backward of S = (x Wg)(y Wh)^T under the reference bound with the
+    rounding points of the 16-bit path (mi_bilinear.hip, separable form): x, y, Wg, Wh and the projections A = x Wg,
+    C = y Wh are rounded to bf16; the exponentials P = exp(S - lse) are rounded to bf16 before the two B x B
+    contractions; dA and dC are rounded to bf16 before the projection gradients."""
+    xb, yb, gb, hb = (round_bf16(t.double()) for t in (x, y, wg, wh))
+    a = round_bf16(xb @ gb)
+    c = round_bf16(yb @ hb)
+    s = a @ c.t()
+    b = s.shape[0]
+    neg = negative_mask(study_id)
+    lse = torch.logsumexp(s[neg], dim=0)
+    loss = bound_from_matrix(s, study_id, estimator)
+    p = round_bf16(torch.where(neg, torch.exp(s - lse), torch.zeros_like(s)))
+    da = round_bf16(p @ c - c / b)
+    dc = round_bf16(p.t() @ a - a / b)
+    return {"scores": s, "loss": loss, "dx": da @ gb.t(), "dy": dc @ hb.t(), "dwg": xb.t() @ da, "dwh": yb.t() @ dc}
+
+
 def separable_scores(x, y, wg, wh) -> torch.Tensor:
     """Extension (no reference code): S = (x Wg)(y Wh)^T."""
     return (x @ wg) @ (y @ wh).t()
@@ -272,15 +291,15 @@ def concat_matrix_step(x, y, study_id, params, estimator: str, round_fn=None, ro
                           study_id, estimator)
         return {"scores": out["scores"], "loss": out["loss"], "dx": out["grads"][0], "dy": out["grads"][1],
                 "dparams": out["grads"][2:]}
-    return _concat_matrix_step_blocked(x, y, study_id, params, estimator, row_block)
+    return _concat_matrix_step_blocked(x, y, study_id, params, estimator, row_block, round_fn)
 
 
-def _concat_matrix_step_blocked(x, y, study_id, params, estimator, rb):
+def _concat_matrix_step_blocked(x, y, study_id, params, estimator, rb, round_fn=None):
     b = x.shape[0]
     neg = negative_mask(study_id)
     n_neg = int(neg.sum())
     with torch.no_grad():
-        blocks = [concat_scores_matrix(x[s:s + rb], y, params) for s in range(0, b, rb)]
+        blocks = [concat_scores_matrix(x[s:s + rb], y, params, round_fn) for s in range(0, b, rb)]
         s_all = torch.cat(blocks, 0)
         lse = torch.logsumexp(s_all[neg], dim=0)
         pos = torch.diagonal(s_all).mean()
@@ -293,7 +312,7 @@ def _concat_matrix_step_blocked(x, y, study_id, params, estimator, rb):
     yl = y.detach().clone().requires_grad_(True)
     pl = [p.detach().clone().requires_grad_(True) for p in params]
     for s in range(0, b, rb):
-        sb = concat_scores_matrix(xl[s:s + rb], yl, pl)
+        sb = concat_scores_matrix(xl[s:s + rb], yl, pl, round_fn)
         (sb * g[s:s + rb]).sum().backward()
     return {"scores": s_all, "loss": loss, "dx": xl.grad, "dy": yl.grad, "dparams": [p.grad for p in pl]}
 

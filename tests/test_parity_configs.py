@@ -1,0 +1,171 @@
+"""Oracle parity on the exact workloads of BASELINE.json's configs and at the sizes where the kernels'
+split plans are not trivial.  Stated tolerances:
+
+  precision="f32" against the fp64 oracle: loss 3e-5 (+1e-5 rel); gradients 3e-4 * max|grad| (+ rtol 2e-3); db3 1e-5.
+  precision="bf16" against the oracle that rounds at the kernel's rounding points: bilinear 1e-2 * max|grad|,
+  concat-MLP 2e-2 * max|grad|; loss 2e-3 * max(1, |S|max) (bilinear) / 3e-3 (concat).
+
+All tests need an MI355X:  python -m pytest tests -m gpu"""
+import math
+import os
+import sys
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import mi_oracle as orc
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def dev():
+    from mutual_info_img_txt import _hip
+    _hip.load()
+    return torch.device("cuda:0")
+
+
+def _dup_ids(b):
+    """SURVEY.md 8d duplicates variant: sid_i = i - (i mod 2) for i < B / 8."""
+    sid = list(range(b))
+    for n in range(max(b // 8, 2)):
+        sid[n] = n - (n % 2)
+    return [str(50000000 + s) for s in sid]
+
+
+# ------------------------------------------------------------------------------------------------ configs[0]
+@pytest.mark.parametrize("dup", [False, True])
+def test_config0_first_step_of_train_py(dev, tmp_path, dup):
+    """configs[0]: `train.py --synthetic --critic bilinear --embed_dim_* 128 --batch_size 64 --mi_estimator dv
+    --precision f32`.  The first training step's loss and gradients against the oracle on the same synthetic batch."""
+    sys.path.insert(0, os.path.join(ROOT, "mutual-information-multimodal_amd"))
+    import multi_modal
+    import train
+    args = train.construct_training_parameters(["--synthetic", "--critic", "bilinear", "--embed_dim_img", "128",
+                                                "--embed_dim_txt", "128", "--batch_size", "64", "--mi_estimator", "dv",
+                                                "--precision", "f32", "--save_directory", str(tmp_path)])
+    from mutual_info_img_txt.main_utils import MultiModalManager
+    torch.manual_seed(0)
+    mgr = MultiModalManager(d_img=128, d_txt=128, critic="bilinear")
+    w = mgr.mi_discriminator.weight.detach().clone()
+    mgr.mi_discriminator.to(dev)
+    img, txt, sid = multi_modal.synthetic_embedding_source(args, dev)(0)
+    if dup:
+        sid = _dup_ids(64)
+    xl, yl = img.clone().requires_grad_(True), txt.clone().requires_grad_(True)
+    loss = mgr.mi_step(xl, yl, sid, args.mi_estimator, args.precision)
+    loss.sum().backward()
+    o = orc.matrix_step(lambda a, c, ww: orc.bilinear_scores(a, c, ww), [img.cpu().double(), txt.cpu().double(), w.double()],
+                        sid, "dv")
+    assert tuple(loss.shape) == (1,)
+    np.testing.assert_allclose(loss.detach().cpu().numpy(), o["loss"].numpy(), rtol=1e-5, atol=3e-5)
+    for got, ref in zip((xl.grad, yl.grad, mgr.mi_discriminator.weight.grad), o["grads"]):
+        np.testing.assert_allclose(got.cpu().numpy(), ref.numpy(), rtol=2e-3, atol=3e-4 * float(ref.abs().max()))
+    # ... and the entry point itself runs that configuration end to end
+    losses = train.train_MI_models(["--synthetic", "--critic", "bilinear", "--embed_dim_img", "128", "--embed_dim_txt", "128",
+                                    "--batch_size", "64", "--mi_estimator", "dv", "--precision", "f32", "--steps_per_epoch",
+                                    "5", "--save_directory", str(tmp_path)])
+    assert len(losses) == 1 and math.isfinite(losses[0])
+
+
+# ------------------------------------------------------------------------------------------------ configs[1]
+@pytest.mark.parametrize("dup", [False, True])
+def test_config1_separable_bf16(dev, dup):
+    """configs[1]: separable critic S = (X Wg)(Y Wh)^T, B=256, d=256, bf16, reference "InfoNCE" semantics, seed 1."""
+    from mutual_info_img_txt import mi_critics
+    from mutual_info_img_txt.model import SeparableCritic
+    b, d = 256, 256
+    gen = torch.Generator().manual_seed(1)
+    x = torch.randn(b, d, generator=gen)
+    y = torch.randn(b, d, generator=gen)
+    torch.manual_seed(1)
+    critic = SeparableCritic(d, d, d)
+    with torch.no_grad():
+        critic.wg.mul_(0.6)
+        critic.wh.mul_(0.6)
+    wg, wh = critic.wg.detach().clone(), critic.wh.detach().clone()
+    critic.to(dev)
+    sid = _dup_ids(b) if dup else [str(n) for n in range(b)]
+    xl, yl = x.to(dev).requires_grad_(True), y.to(dev).requires_grad_(True)
+    loss, stats = mi_critics.fused_mi_bound(xl, yl, sid, critic, "infonce", precision="bf16", return_stats=True)
+    loss.backward()
+    from mutual_info_img_txt import _hip
+    assert _hip.stats_dict(stats)["n_neg"] == int(orc.negative_mask(sid).sum()) and tuple(loss.shape) == ()
+    o = orc.separable_step_rounded(x, y, wg, wh, sid, "infonce")
+    sc = float(o["scores"].abs().max())
+    assert abs(float(loss) - float(o["loss"])) < 2e-3 * max(sc, 1.0)
+    for name, got, ref in (("dx", xl.grad, o["dx"]), ("dy", yl.grad, o["dy"]), ("dwg", critic.wg.grad, o["dwg"]),
+                           ("dwh", critic.wh.grad, o["dwh"])):
+        err = float((got.cpu().double() - ref).abs().max()) / float(ref.abs().max())
+        assert err < 1.5e-2, (name, err)
+
+
+# ------------------------------------------------------------------------------------------------ fp32 parity at size
+@pytest.mark.parametrize("b,d", [(1024, 512), (4096, 512)])
+def test_bilinear_f32_full_size_vs_fp64_oracle(dev, b, d):
+    """The parity mode at BASELINE configs 3 / 4 sizes (it was only exercised at B <= 200 before)."""
+    from mutual_info_img_txt import mi_critics
+    from mutual_info_img_txt.model import BilinearCritic
+    gen = torch.Generator().manual_seed(b)
+    x = torch.randn(b, d, generator=gen)
+    y = torch.randn(b, d, generator=gen)
+    w = torch.randn(d, d, generator=gen) * (0.3 / math.sqrt(d))
+    sid = _dup_ids(b)
+    critic = BilinearCritic(d, d)
+    with torch.no_grad():
+        critic.weight.copy_(w)
+    critic.to(dev)
+    xl, yl = x.to(dev).requires_grad_(True), y.to(dev).requires_grad_(True)
+    loss = mi_critics.fused_mi_bound(xl, yl, sid, critic, "dv", precision="f32")
+    loss.sum().backward()
+    o = orc.matrix_step(lambda a, c, ww: orc.bilinear_scores(a, c, ww), [x.double(), y.double(), w.double()], sid, "dv")
+    np.testing.assert_allclose(loss.detach().cpu().numpy(), o["loss"].numpy(), rtol=1e-5, atol=3e-5)
+    for name, got, ref in zip(("dx", "dy", "dw"), (xl.grad, yl.grad, critic.weight.grad), o["grads"]):
+        np.testing.assert_allclose(got.cpu().numpy(), ref.numpy(), rtol=2e-3, atol=3e-4 * float(ref.abs().max()), err_msg=name)
+
+
+GRAD_NAMES = ["dx", "dy", "dw1", "db1", "dw2", "db2", "dw3", "db3"]
+
+
+def _concat_all_grads(dev, x, y, sid, params, hidden, est, precision):
+    from mutual_info_img_txt import mi_critics
+    from mutual_info_img_txt.model import make_mlp
+    mlp = make_mlp(x.shape[1] + y.shape[1], list(hidden))
+    with torch.no_grad():
+        for p, v in zip(mlp.parameters(), params):
+            p.copy_(v)
+    mlp.to(dev)
+    xl, yl = x.to(dev).requires_grad_(True), y.to(dev).requires_grad_(True)
+    loss = mi_critics.fused_mi_bound(xl, yl, sid, mlp, est, precision=precision)
+    loss.sum().backward()
+    torch.cuda.synchronize()
+    return loss.detach().cpu(), [g.cpu() for g in [xl.grad, yl.grad] + [p.grad for p in mlp.parameters()]]
+
+
+# B > 1024 makes plan_concat split rows over workgroups (rows_per_msplit > 1, rows_per_dsplit > 16, several i-blocks
+# and j-splits): the multi-row paths of the db2 / dw2 / finish_w2 / dV-slab / split-K dW1 kernels, with small widths so
+# that the fp64 oracle stays cheap.  And the reference's own widths (h = 1024 / 512) at B = 512, d = 768.
+@pytest.mark.parametrize("b,d,h1,h2,rb", [(1536, 32, 64, 256, 128), (2048, 32, 64, 256, 128), (512, 768, 1024, 512, 64)])
+@pytest.mark.parametrize("precision", ["f32", "bf16"])
+def test_concat_all_gradients_at_size(dev, b, d, h1, h2, rb, precision):
+    x, y, _, params = orc.synthetic_case(b, d, d, h1=h1, h2=h2, salt=b // 8)
+    sid = _dup_ids(b)
+    loss, grads = _concat_all_grads(dev, x, y, sid, params, (h1, h2), "dv", precision)
+    p64 = [p.double() for p in params]
+    rf = orc.round_bf16 if precision == "bf16" else None
+    o = orc.concat_matrix_step(x.double(), y.double(), sid, p64, "dv", round_fn=rf, row_block=rb)
+    sc = max(float(o["scores"].abs().max()), 1.0)
+    assert abs(float(loss) - float(o["loss"])) < (3e-5 + 1e-5 * abs(float(o["loss"])) if precision == "f32" else 3e-3 * sc)
+    refs = [o["dx"], o["dy"]] + list(o["dparams"])
+    for name, got, ref in zip(GRAD_NAMES, grads, refs):
+        ref = ref.reshape(got.shape)
+        scale = 1.0 if name == "db3" else float(ref.abs().max())
+        if precision == "f32":
+            np.testing.assert_allclose(got.numpy(), ref.numpy(), rtol=2e-3, atol=(1e-5 if name == "db3" else 3e-4) * scale,
+                                       err_msg=name)
+        else:
+            err = float((got.double() - ref).abs().max()) / scale
+            assert err < (2e-5 if name == "db3" else 2e-2), (name, err)
