@@ -579,14 +579,23 @@ __global__ __launch_bounds__(256, 1) void bilinear_flash_kernel(FlashArgs args) 
       }
     };
     fl_static_for<0, kFlAhead>([&](auto NI) __attribute__((always_inline)) { issue_read(NI); });
-    // score product + softmax slices
+    // The head of the softmax (mask, tile maximum, reference-point decision: slices [0, HEAD)) runs right here, in the
+    // shadow of the first fragment reads' LDS latency; the exponentials and the bf16 packing go one slice per MFMA gap.
+    constexpr int HEAD = 10;
+    if constexpr (DO_SM && HAS_S) {
+      fl_static_for<0, HEAD>([&](auto SI) __attribute__((always_inline)) { sm_slice(SI, tp); });
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // score product + the remaining softmax slices
     fl_static_for<0, NS>([&](auto NI) __attribute__((always_inline)) {
       constexpr int n = decltype(NI)::value;
       fl_mfma_s<(n < C::QA), n == 0, fl_wait_count<NS, NV>(n)>(s_next, ring[n % kFlRing], qf[n]);
       issue_read(std::integral_constant<int, n + kFlAhead>{});
       if constexpr (DO_SM) {
-        constexpr int per = (NSL + (NS > 0 ? NS : 1) - 1) / (NS > 0 ? NS : 1);  // slices per gap (1 at D = 512, 2 at 256, 4 at 128)
-        fl_static_for<n * per, (n * per + per < NSL ? n * per + per : NSL)>([&](auto SI) __attribute__((always_inline)) { sm_slice(SI, tp); });
+        constexpr int NSD = NS > 0 ? NS : 1;
+        constexpr int per = (NSL - HEAD + NSD - 1) / NSD;  // slices per gap (1 at D = 512, 2 at 256, 3 at 128)
+        constexpr int lo = HEAD + n * per, hi = (lo + per < NSL ? lo + per : NSL);
+        fl_static_for<(lo < NSL ? lo : NSL), hi>([&](auto SI) __attribute__((always_inline)) { sm_slice(SI, tp); });
       }
       __builtin_amdgcn_sched_barrier(0);
     });
