@@ -66,7 +66,7 @@ static BilinearPlan plan_bilinear(Workspace& ws, int64_t br, int64_t b, int64_t 
   if (precision == MI_PREC_BF16 && br % 8 == 0 && b % 8 == 0 && dx % 8 == 0) p.fl = flash_plan(br, b, dy);
   for (int q = 0; q < 2; ++q) {
     p.fl_rec[q] = p.fl.ok ? ws.take<Partial>(p.fl.n_rec[q]) : nullptr;
-    p.fl_slab[q] = p.fl.ok ? ws.take<float>(p.fl.slab_floats[q]) : nullptr;
+    p.fl_slab[q] = p.fl.ok ? ws.take<float>((p.fl.slab_bytes[q] + 3) / 4) : nullptr;
     p.fl_dup[q] = p.fl.ok ? ws.take<unsigned char>((br / 32) * (b / 32)) : nullptr;
   }
   p.tfb = p.fl.ok ? ws.take<bf16_t>(br * dy) : nullptr;
@@ -121,6 +121,16 @@ static int fast_prep_and_t(const float* x, const float* y, const float* w, const
                            hipStream_t st) {
   // With the fused B x B kernel nobody reads Y^T or T^T any more; instead T and Y get a fragment-major copy (the
   // kernel's stationary operand, loaded straight into MFMA B fragments) and the equal-id tile flags ride along.
+  if (p.fl.ok) {
+    // one launch: T tiles straight from the fp32 operands, the other conversions on the CUs the tiles leave free
+    CvtJobs side{};
+    side.j[0] = CvtJob{x, br, dx, nullptr, p.xtb, 0, 0, nullptr};
+    side.j[1] = CvtJob{y, b, dy, p.yb, nullptr, 0, 0, p.yfb};
+    side.j[2] = CvtJob{w, dx, dy, p.wb, nullptr, 0, 0, nullptr};
+    side.dup = DupFlagJob{sid_rows, sid_cols, (int)(br / 32), (int)(b / 32), p.fl_dup[0], p.fl_dup[1]};
+    const int rc1 = launch_prep_t(x, w, br, dy, dx, p.tb, p.tfb, side, st, "bilinear prep + T = X W");
+    if (rc1 != MI_EINVAL) return rc1;
+  }
   CvtJobs jobs{};
   jobs.j[0] = CvtJob{x, br, dx, p.xb, p.xtb, 0, 0, nullptr};
   jobs.j[1] = CvtJob{y, b, dy, p.yb, p.fl.ok ? nullptr : p.ytb, 0, 0, p.fl.ok ? p.yfb : nullptr};
@@ -148,6 +158,7 @@ static int flash_stage(const int64_t* sid_rows, const int64_t* sid_cols, int64_t
   a.p[1] = FlashProblem{p.yfb, p.tb, sid_cols, sid_rows, b, br, -row_offset, p.fl.n_rb[1], p.fl.n_split[1],
                         p.fl.tiles_per_split[1], p.fl_dup[1], p.fl_slab[1], p.fl_rec[1]};
   a.n_problems = grad ? 2 : 1;
+  a.slab_f16 = p.fl.slab_f16 ? 1 : 0;
   return launch_flash(a, dy, grad, st, grad ? "bilinear fused S | P Y | P^T T" : "bilinear fused S + LSE");
 }
 
@@ -189,7 +200,7 @@ static int bilinear_bwd_fast(const int64_t* sid_rows, const int64_t* sid_cols, i
                              grad_y, nullptr, nullptr};
     ra.stats = stats;
     ra.grad_out = grad_out;
-    rc = launch_flash_reduce(ra, 2, dy, st, "bilinear dT, dY from the fused sums");
+    rc = launch_flash_reduce(ra, 2, dy, p.fl.slab_f16, st, "bilinear dT, dY from the fused sums");
     if (rc) return rc;
     return bilinear_bwd_small(br, dx, dy, grad_x, grad_w, p, st);
   }
@@ -466,7 +477,7 @@ static SeparablePlan plan_separable(Workspace& ws, int64_t br, int64_t b, int64_
     p.dctb = ws.take<bf16_t>(b * k);
     for (int q = 0; q < 2; ++q) {
       p.rec[q] = ws.take<Partial>(p.fl.n_rec[q]);
-      p.slab[q] = ws.take<float>(p.fl.slab_floats[q]);
+      p.slab[q] = ws.take<float>((p.fl.slab_bytes[q] + 3) / 4);
       p.dup[q] = ws.take<unsigned char>((br / 32) * (b / 32));
     }
     split_plan(br, dx, k, p.wg_splits, p.wg_kchunk);
@@ -518,6 +529,7 @@ static int separable_flash(const int64_t* sid_rows, const int64_t* sid_cols, int
   a.p[1] = FlashProblem{p.cfb, p.ab, sid_cols, sid_rows, b, br, -row_offset, p.fl.n_rb[1], p.fl.n_split[1],
                         p.fl.tiles_per_split[1], p.dup[1], p.slab[1], p.rec[1]};
   a.n_problems = grad ? 2 : 1;
+  a.slab_f16 = p.fl.slab_f16 ? 1 : 0;
   return launch_flash(a, k, grad, st, grad ? "separable fused S | P C | P^T A" : "separable fused S + LSE");
 }
 
@@ -614,7 +626,7 @@ int mi_separable_bwd(const float* x, const float* y, const float* wg, const floa
                              p.dctb};
     ra.stats = stats;
     ra.grad_out = grad_out;
-    rc = launch_flash_reduce(ra, 2, k, st, "separable dA, dC from the fused sums");
+    rc = launch_flash_reduce(ra, 2, k, p.fl.slab_f16, st, "separable dA, dC from the fused sums");
     if (rc) return rc;
     // per modality: dW[a, c] = sum_i X[i, a] dA[i, c] (split over i into slabs) | dX[i, a] = sum_c dA[i, c] W[a, c]
     auto pair = [&](const bf16_t* xt, const bf16_t* dat, const bf16_t* da, const bf16_t* wb, int64_t rows, int64_t d,

@@ -26,9 +26,12 @@
 //     conflict-free).
 // The streamed range is split over `n_split` workgroups per row block so that ~256 workgroups fill the chip; every
 // (problem, split) pair is pinned to one XCD (L % n_combo), whose 4 MB L2 then holds the streamed rows all its
-// workgroups sweep.  Partial O tiles go to fp32 slabs in accumulator order (16-byte stores, 1 KB per wave store) with
-// the wave's (m_ref, sum, positives, count) record; `flash_reduce_kernel` adds the slabs in a fixed order with the global
-// lse -- bit-reproducible, no float atomics.
+// workgroups sweep.  Partial O tiles go to slabs in accumulator order (16-byte stores, 1 KB per wave store) with the
+// wave's (m_ref, sum, positives, count) record; `flash_reduce_kernel` adds the slabs in a fixed order with the global
+// lse -- bit-reproducible, no float atomics.  The slabs are the step's largest HBM traffic (fp32: 64 MB written and read
+// back at B = 4096, d = 512), so by default a wave stores its tile as fp16 under one power-of-two scale of its own
+// (largest element in [2^13, 2^14); the factor back sits behind the slabs): 11 significant bits on partial sums whose
+// addends were rounded to 8 (P and the operands are bf16), half the traffic.  MI_FLASH_SLAB_F32=1 keeps fp32 slabs.
 #pragma once
 #include <type_traits>
 
@@ -65,7 +68,8 @@ struct FlashProblem {
   int n_split;            // workgroups per row block
   int tiles_per_split;
   const unsigned char* dup;  // [m / 32][n / 32]: 1 iff the 32 x 32 block holds a pair with equal study ids
-  float* slab;            // [n_split][n_rb][4 waves][32 * D] partial sums in accumulator order
+  float* slab;            // [n_split][n_rb][4 waves][32 * D] partial sums in accumulator order: fp32, or (slab_f16) fp16
+                          // followed by one fp32 factor per wave [n_split][n_rb][4] that undoes the wave's scale
   Partial* rec;           // [n_split][n_rb][4]
 };
 struct FlashArgs {
@@ -75,6 +79,7 @@ struct FlashArgs {
   int xcd_rows; // 1: (problem, row block) units pinned to XCDs; 0: (problem, split) pairs pinned to XCDs
   int diag;     // diagnostic (MI_STAMPS) builds only, timing experiments with WRONG results: bit 0 no LDS-DMA in the loop,
                 // bit 1 no softmax slices, bit 2 no workgroup barrier in the loop (MI_FLASH_DIAG in the environment)
+  int slab_f16; // 1: scaled fp16 slabs (see FlashProblem::slab)
 };
 
 template <int D>
@@ -656,8 +661,34 @@ __global__ __launch_bounds__(256, 1) void bilinear_flash_kernel(FlashArgs args) 
   }
   if constexpr (GRAD) {
     fl_mfma_drain_all();
-    if (wave_active) {
-      float* dst = P.slab + (((int64_t)split * P.n_rb + rb) * 4 + wave) * (32 * D) + lane * 4;
+    const int64_t wv = ((int64_t)split * P.n_rb + rb) * 4 + wave;
+    if (wave_active && args.slab_f16) {
+      // one power-of-two scale per wave: the largest |element| lands in [2^13, 2^14), fp16's range is never left and
+      // every element within 2^-27 of the largest keeps its 11 bits (smaller ones cannot matter to the sum)
+      float amax = 0.0f;
+#pragma unroll
+      for (int c = 0; c < C::NT; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) amax = fmaxf(amax, __builtin_fabsf(o[c][r]));
+      amax = wave_max_uniform(amax);
+      int k = 13 - ((int)((__float_as_uint(amax) >> 23) & 255u) - 127);
+      k = amax > 0.0f ? (k < -100 ? -100 : (k > 100 ? 100 : k)) : 0;
+      const float up = __uint_as_float((unsigned)(127 + k) << 23), down = __uint_as_float((unsigned)(127 - k) << 23);
+      f16_t* slab16 = reinterpret_cast<f16_t*>(P.slab);
+      float* unscale = reinterpret_cast<float*>(slab16 + (int64_t)P.n_split * P.n_rb * 4 * (32 * D));
+      if (lane == 0) unscale[wv] = down;
+      f16_t* dst = slab16 + wv * (32 * D) + lane * 8;
+#pragma unroll
+      for (int c = 0; c < C::NT; ++c)
+#pragma unroll
+        for (int gp = 0; gp < 2; ++gp) {
+          f16x8 h;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) h[e] = (f16_t)(o[c][8 * gp + e] * up);
+          *reinterpret_cast<f16x8*>(dst + c * 1024 + gp * 512) = h;
+        }
+    } else if (wave_active) {
+      float* dst = P.slab + wv * (32 * D) + lane * 4;
 #pragma unroll
       for (int c = 0; c < C::NT; ++c)
 #pragma unroll
@@ -740,7 +771,7 @@ struct FlashReduceArgs {
   const float* grad_out;
 };
 
-template <int D>
+template <int D, bool F16>
 __global__ __launch_bounds__(256) void flash_reduce_kernel(FlashReduceArgs args) {
   kernarg_prefetch<(int)sizeof(FlashReduceArgs)>();
   __shared__ float tile[32][129];
@@ -753,29 +784,80 @@ __global__ __launch_bounds__(256) void flash_reduce_kernel(FlashReduceArgs args)
   const float lse = args.stats->lse;
   const float gpos = go / (float)args.stats->n_pos;
   const int tid = threadIdx.x;
-  f32x4 acc[4];
+  float acc[16];
 #pragma unroll
-  for (int u = 0; u < 4; ++u) acc[u] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-  for (int s = 0; s < J.n_split; ++s) {
-    const int64_t wv = ((int64_t)s * J.n_rb + rb) * 4 + w;
-    const float m = J.rec[wv].m;
-    if (!(m > MI_NEG_INF)) continue;  // nothing accumulated by that wave
-    const float c = go * __expf(m - lse);
-    const float* src = J.slab + wv * (32 * D) + (int64_t)cc * 4 * 1024;
+  for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
+  const f16_t* slab16 = reinterpret_cast<const f16_t*>(J.slab);
+  const float* unscale = reinterpret_cast<const float*>(slab16 + (int64_t)J.n_split * J.n_rb * 4 * (32 * D));
+  // four splits per round: their loads are independent and issued together, the additions keep the split order.  A wave
+  // that accumulated nothing (m = -inf) left its slab unwritten: its factor is 0 and its values are not touched.
+  for (int s0 = 0; s0 < J.n_split; s0 += 4) {
+    float cs[4];
+    int64_t wvs[4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const f32x4 v = *reinterpret_cast<const f32x4*>(src + (u * 256 + tid) * 4);
-      acc[u] += v * c;
+    for (int q = 0; q < 4; ++q) {
+      const int s = s0 + q < J.n_split ? s0 + q : J.n_split - 1;
+      wvs[q] = ((int64_t)s * J.n_rb + rb) * 4 + w;
+      const float m = J.rec[wvs[q]].m;
+      cs[q] = (s0 + q < J.n_split && m > MI_NEG_INF) ? go * __expf(m - lse) * (F16 ? unscale[wvs[q]] : 1.0f) : 0.0f;
+    }
+    if constexpr (F16) {
+      f16x8 v[4][2];
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+          v[q][u] = *reinterpret_cast<const f16x8*>(slab16 + wvs[q] * (32 * D) + (int64_t)cc * 4096 + (u * 256 + tid) * 8);
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (cs[q] != 0.0f) {
+#pragma unroll
+          for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[8 * u + e] += (float)v[q][u][e] * cs[q];
+        }
+    } else {
+      f32x4 v[4][4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          v[q][u] = *reinterpret_cast<const f32x4*>(J.slab + wvs[q] * (32 * D) + (int64_t)cc * 4096 + (u * 256 + tid) * 4);
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (cs[q] != 0.0f) {
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[4 * u + e] += v[q][u][e] * cs[q];
+        }
     }
   }
-  // element (u, tid): float4 index f = u * 256 + tid = ct_l * 256 + g * 64 + lane
+  if constexpr (F16) {
+    // 16-byte chunk h = u * 256 + tid = ct_l * 128 + gp * 64 + lane holds accumulator registers 8 gp .. 8 gp + 7 of the
+    // lane: rows 8 g + 4 (lane >> 5) + e for g = 2 gp and 2 gp + 1, column ct_l * 32 + (lane & 31)
 #pragma unroll
-  for (int u = 0; u < 4; ++u) {
-    const int f = u * 256 + tid;
-    const int ct_l = f >> 8, g = (f >> 6) & 3, lane = f & 63;
-    const int col = ct_l * 32 + (lane & 31), row0 = 8 * g + 4 * (lane >> 5);
+    for (int u = 0; u < 2; ++u) {
+      const int h = u * 256 + tid;
+      const int ct_l = h >> 7, gp = (h >> 6) & 1, lane = h & 63;
+      const int col = ct_l * 32 + (lane & 31);
 #pragma unroll
-    for (int e = 0; e < 4; ++e) tile[row0 + e][col] = acc[u][e];
+      for (int hh = 0; hh < 2; ++hh) {
+        const int row0 = 8 * (2 * gp + hh) + 4 * (lane >> 5);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) tile[row0 + e][col] = acc[8 * u + 4 * hh + e];
+      }
+    }
+  } else {
+    // float4 index f = u * 256 + tid = ct_l * 256 + g * 64 + lane
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int f = u * 256 + tid;
+      const int ct_l = f >> 8, g = (f >> 6) & 3, lane = f & 63;
+      const int col = ct_l * 32 + (lane & 31), row0 = 8 * g + 4 * (lane >> 5);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) tile[row0 + e][col] = acc[4 * u + e];
+    }
   }
   __syncthreads();
   const int64_t i0 = wb * 32;
@@ -834,7 +916,8 @@ __global__ __launch_bounds__(256) void flash_reduce_kernel(FlashReduceArgs args)
 struct FlashPlan {
   bool ok;
   int n_split[2], n_rb[2], tiles_per_split[2];
-  int64_t slab_floats[2], n_rec[2];
+  int64_t slab_bytes[2], n_rec[2];
+  bool slab_f16;
 };
 
 static inline bool flash_width_ok(int64_t d) { return d == 128 || d == 256 || d == 512; }
@@ -845,6 +928,8 @@ static inline FlashPlan flash_plan(int64_t br, int64_t b, int64_t d) {
   static const bool off = getenv("MI_NO_FLASH") != nullptr;  // A/B switch: the round-1 G-materialising path
   fp.ok = !off && flash_width_ok(d) && br % 32 == 0 && b % 32 == 0 && br >= 32;
   if (!fp.ok) return fp;
+  static const bool slab_f32 = getenv("MI_FLASH_SLAB_F32") != nullptr;  // A/B switch: fp32 partial sums
+  fp.slab_f16 = !slab_f32;
   const int64_t m[2] = {br, b}, n[2] = {b, br};
   int64_t total_tiles = 0;
   for (int q = 0; q < 2; ++q) {
@@ -862,7 +947,7 @@ static inline FlashPlan flash_plan(int64_t br, int64_t b, int64_t d) {
     fp.tiles_per_split[q] = (int)((tiles + fp.n_split[q] - 1) / fp.n_split[q]);  // balanced
     fp.n_split[q] = (int)((tiles + fp.tiles_per_split[q] - 1) / fp.tiles_per_split[q]);
     fp.n_rec[q] = (int64_t)fp.n_split[q] * fp.n_rb[q] * 4;
-    fp.slab_floats[q] = fp.n_rec[q] * 32 * d;
+    fp.slab_bytes[q] = fp.slab_f16 ? fp.n_rec[q] * (32 * d * 2 + 4) : fp.n_rec[q] * 32 * d * 4;
   }
   return fp;
 }
@@ -905,15 +990,20 @@ static inline int launch_flash(FlashArgs a, int64_t d, bool grad, hipStream_t st
   return MI_ESHAPE;
 }
 
-static inline int launch_flash_reduce(const FlashReduceArgs& a, int n_jobs, int64_t d, hipStream_t st, const char* what) {
+static inline int launch_flash_reduce(const FlashReduceArgs& a, int n_jobs, int64_t d, bool slab_f16, hipStream_t st,
+                                      const char* what) {
   int64_t mmax = a.j[0].m;
   if (n_jobs == 2 && a.j[1].m > mmax) mmax = a.j[1].m;
   dim3 grid((unsigned)(d / 128), (unsigned)(mmax / 32), (unsigned)n_jobs);
   {
     ProfScope prof_(what, st);
-    if (d == 512) hipLaunchKernelGGL(flash_reduce_kernel<512>, grid, dim3(256), 0, st, a);
-    else if (d == 256) hipLaunchKernelGGL(flash_reduce_kernel<256>, grid, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL(flash_reduce_kernel<128>, grid, dim3(256), 0, st, a);
+#define MI_FL_REDUCE(DD)                                                                                  \
+  if (slab_f16) hipLaunchKernelGGL((flash_reduce_kernel<DD, true>), grid, dim3(256), 0, st, a);           \
+  else hipLaunchKernelGGL((flash_reduce_kernel<DD, false>), grid, dim3(256), 0, st, a)
+    if (d == 512) { MI_FL_REDUCE(512); }
+    else if (d == 256) { MI_FL_REDUCE(256); }
+    else { MI_FL_REDUCE(128); }
+#undef MI_FL_REDUCE
   }
   MI_LAUNCH_CHECK(what);
   return MI_OK;

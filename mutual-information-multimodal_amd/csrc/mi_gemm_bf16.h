@@ -101,6 +101,12 @@ static inline void xcd_pick_blocks(int64_t ny, int64_t nx, int64_t tile, int64_t
   }
 }
 
+template <int N>
+__device__ __forceinline__ void wait_vmcnt_barrier_n() {
+  // counted wait for this wave's own LDS-DMA pieces, then the workgroup barrier (a __syncthreads would drain vmcnt to 0)
+  asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
+}
+
 struct GemmBf16Problem {
   const bf16_t* a;
   int64_t lda;
@@ -669,6 +675,134 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_glds_kernel(GemmBf16Args arg
   epi(acc, m0 + wm * 64, n0 + wn * 64, P.m, P.n, prob, zsplit, smem_raw + wave * kEpiLdsPerWave);
 }
 
+// Four-stage form of the kernel above for the SHORT-K products (T = X W, dX = dT W^T, the split-K slices of dW: eight
+// 64-deep steps each).  With two stages and one __syncthreads per step (which drains vmcnt to 0) every step waits out the
+// L2 latency of the tile issued at its start (~1,800 cycles per step, stamps of round 1, against 512 cycles of MFMA);
+// here three tiles are in flight behind counted waits (s_waitcnt vmcnt(pieces still allowed in flight) + bare
+// s_barrier), 128 KB of LDS, one workgroup per CU.
+template <class Epi>
+__global__ __launch_bounds__(256, 1) void gemm_bf16_glds4_kernel(GemmBf16Args args, Epi epi) {
+  kernarg_prefetch<(int)(sizeof(GemmBf16Args) + sizeof(Epi))>();
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  // [buf][A | B][128 rows][128 bytes]
+  int prob, zsplit, bx_, by_;
+  int64_t k_chunk = args.k_chunk;
+  if (args.flat) {
+    const int L = (int)blockIdx.x;
+    prob = (args.n_problems == 2 && L >= args.p[1].wg_begin) ? 1 : 0;
+    const GemmBf16Problem& Q = args.p[prob];
+    const int local = L - Q.wg_begin, tiles = Q.nx * Q.ny;
+    zsplit = local / tiles;
+    xcd_tile_lin(local - zsplit * tiles, Q.nx, Q.ny, bx_, by_);
+    k_chunk = Q.k_chunk;
+  } else {
+    prob = (int)blockIdx.z % args.n_problems;
+    zsplit = (int)blockIdx.z / args.n_problems;
+    if (args.xcd_gy) xcd_block_tile(args.xcd_gy, args.xcd_gx, bx_, by_);
+    else xcd_tile(bx_, by_);
+  }
+  const GemmBf16Problem& P = args.p[prob];
+  const int64_t m0 = (int64_t)by_ * kTile, n0 = (int64_t)bx_ * kTile;
+  if (m0 >= P.m || n0 >= P.n) return;
+  const int64_t kbeg = (int64_t)zsplit * k_chunk;
+  if (kbeg >= P.k) return;  // flat launches: padding ids between the problems' ranges
+  int64_t kend = kbeg + k_chunk;
+  if (kend > P.k) kend = P.k;
+
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int r32 = lane & 31, half = lane >> 5;
+
+  // staging: wave w, instruction i (0..3): rows 32 w + 8 i + (lane >> 3), LDS chunk position lane & 7
+  constexpr int NI = 4;
+  const char* asrc[NI];
+  const char* bsrc[NI];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int row = 8 * NI * wave + 8 * i + (lane >> 3);
+    const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+    int64_t am = m0 + row, bn = n0 + row;
+    if (am >= P.m) am = P.m - 1;
+    if (bn >= P.n) bn = P.n - 1;
+    asrc[i] = reinterpret_cast<const char*>(P.a + am * P.lda + kbeg) + chunk * 16;
+    bsrc[i] = reinterpret_cast<const char*>(P.b + bn * P.ldb + kbeg) + chunk * 16;
+  }
+  auto issue_tile = [&](int64_t t, int buf) {
+    char* abase = smem_raw + buf * 32768 + (8 * NI * wave) * 128;
+    char* bbase = abase + 16384;
+    const int64_t koff = t * (kG2KT * 2);  // bytes
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(asrc[i] + koff),
+                                       (__attribute__((address_space(3))) void*)(abase + i * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bsrc[i] + koff),
+                                       (__attribute__((address_space(3))) void*)(bbase + i * 1024), 16, 0, 0);
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+
+  // fragment read offsets (bytes within a 16 KB operand tile), per kk the chunk index is 2 kk + half
+  int aoff[2], boff[2], aswz[2], bswz[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int ar = wm * 64 + t * 32 + r32, br_ = wn * 64 + t * 32 + r32;
+    aoff[t] = ar * 128;
+    boff[t] = br_ * 128;
+    aswz[t] = (ar >> 1) & 7;
+    bswz[t] = (br_ >> 1) & 7;
+  }
+
+  constexpr int KK = kG2KT / 16;  // 16-deep MFMA steps per K tile
+  constexpr int kk0 = 0;
+  constexpr int NST = 4, PCS = 2 * NI;  // stages; LDS-DMA pieces per wave and tile
+  const int64_t nt = (kend - kbeg) / kG2KT;
+  for (int t = 0; t < NST - 1; ++t)
+    if (t < nt) issue_tile(t, t);
+  for (int64_t t = 0; t < nt; ++t) {
+    const int buf = (int)(t & (NST - 1));
+    // tile t landed (own pieces: all but the younger tiles' may stay in flight), then everybody's; every wave has left
+    // tile t - 1, whose stage the issue below refills
+    const int64_t younger = nt - 1 - t < NST - 2 ? nt - 1 - t : NST - 2;
+    if (younger >= 2) wait_vmcnt_barrier_n<2 * PCS>();
+    else if (younger == 1) wait_vmcnt_barrier_n<PCS>();
+    else wait_vmcnt_barrier_n<0>();
+    if (t + NST - 1 < nt) issue_tile(t + NST - 1, (int)((t + NST - 1) & (NST - 1)));
+    const char* at = smem_raw + buf * 32768;
+    const char* bt = at + 16384;
+    bf16x8 af[2][2], bfr[2][2];
+    auto read_frags = [&](int kk, int slot) {
+#pragma unroll
+      for (int tm = 0; tm < 2; ++tm)
+        af[slot][tm] = *reinterpret_cast<const bf16x8*>(at + aoff[tm] + 16 * ((2 * kk + half) ^ aswz[tm]));
+#pragma unroll
+      for (int tn = 0; tn < 2; ++tn)
+        bfr[slot][tn] = *reinterpret_cast<const bf16x8*>(bt + boff[tn] + 16 * ((2 * kk + half) ^ bswz[tn]));
+    };
+    read_frags(kk0, 0);
+#pragma unroll
+    for (int q = 0; q < KK; ++q) {
+      if (q + 1 < KK) read_frags(kk0 + q + 1, (q + 1) & 1);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn)
+          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[q & 1][tm], bfr[q & 1][tn], acc[tm][tn], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  __syncthreads();  // all fragment reads done: the stages are free for the epilogue's staging areas
+  epi(acc, m0 + wm * 64, n0 + wn * 64, P.m, P.n, prob, zsplit, smem_raw + wave * kEpiLdsPerWave);
+}
+
 // ------------------------------------------------------------------------------------------------ pipelined kernel
 // In-kernel s_memtime stamps of the double-buffered kernels above (profiles/README.md): a 128 x 128 x 64 step took
 // ~1,800 cycles against 512 cycles of MFMA per SIMD.  The time goes to ISSUING the LDS-DMA pieces (a wave is held
@@ -1043,6 +1177,10 @@ static inline bool gemm_old_kernels() {  // A/B switch: the double-buffered kern
   static const bool v = getenv("MI_GEMM_OLD") != nullptr;
   return v;
 }
+static inline bool gemm_use_glds4() {  // A/B switch: the two-stage kernel instead of the four-stage one
+  static const bool off = getenv("MI_GEMM_NO_GLDS4") != nullptr;
+  return !off;
+}
 static inline bool gemm_bf16_use_big(int64_t m, int64_t n, int64_t k) {
   static const bool off = getenv("MI_GEMM_NO_BIG") != nullptr;
   return !off && k % kG2KT == 0 && k > 0 && ((m + 255) / 256) * ((n + 255) / 256) >= 192;
@@ -1070,6 +1208,7 @@ static inline int launch_gemm_bf16(const GemmBf16Args& args_in, int n_splits, co
   // per Epi instantiation, per device, thread-safe (mi_common.h)
   MI_SET_DYN_SMEM((gemm_bf16_kernel<Epi>), kG2Smem, "hipFuncSetAttribute(gemm_bf16_kernel)");
   MI_SET_DYN_SMEM((gemm_bf16_glds_kernel<Epi>), kG2SmemGlds, "hipFuncSetAttribute(gemm_bf16_glds_kernel)");
+  MI_SET_DYN_SMEM((gemm_bf16_glds4_kernel<Epi>), 2 * kG2SmemGlds, "hipFuncSetAttribute(gemm_bf16_glds4_kernel)");
   if constexpr (!Epi::kReducesPartial)
     MI_SET_DYN_SMEM((gemm_bf16_pipe_kernel<PipeCfg128, Epi>), PipeCfg128::SMEM,
                     "hipFuncSetAttribute(gemm_bf16_pipe_kernel 128)");
@@ -1103,7 +1242,9 @@ static inline int launch_gemm_bf16(const GemmBf16Args& args_in, int n_splits, co
         hipLaunchKernelGGL((gemm_bf16_pipe_kernel<PipeCfg128, Epi>), grid, dim3(512), PipeCfg128::SMEM, st, args, epi);
     }
     if (piped) {
-    } else if (dma_ok) hipLaunchKernelGGL((gemm_bf16_glds_kernel<Epi>), grid, dim3(256), kG2SmemGlds, st, args, epi);
+    } else if (dma_ok && gemm_use_glds4() && args.p[0].k >= 4 * kG2KT && (int64_t)grid.x * grid.y * grid.z <= 512)
+      hipLaunchKernelGGL((gemm_bf16_glds4_kernel<Epi>), grid, dim3(256), 2 * kG2SmemGlds, st, args, epi);
+    else if (dma_ok) hipLaunchKernelGGL((gemm_bf16_glds_kernel<Epi>), grid, dim3(256), kG2SmemGlds, st, args, epi);
     else hipLaunchKernelGGL((gemm_bf16_kernel<Epi>), grid, dim3(256), kG2Smem, st, args, epi);
   }
   MI_LAUNCH_CHECK(what);
@@ -1130,13 +1271,15 @@ static inline int launch_gemm_bf16_flat(const GemmBf16Args& args_in, const int (
   }
   if (!ok) return MI_EINVAL;
   MI_SET_DYN_SMEM((gemm_bf16_glds_kernel<Epi>), kG2SmemGlds, "hipFuncSetAttribute(gemm_bf16_glds_kernel)");
+  MI_SET_DYN_SMEM((gemm_bf16_glds4_kernel<Epi>), 2 * kG2SmemGlds, "hipFuncSetAttribute(gemm_bf16_glds4_kernel)");
   args.flat = 1;
   args.xcd_gy = args.xcd_gx = 0;
   args.k_chunk = 0;
   MI_STAMP_SELECT(what, st);
   {
     ProfScope prof_(what, st);
-    hipLaunchKernelGGL((gemm_bf16_glds_kernel<Epi>), dim3((unsigned)total), dim3(256), kG2SmemGlds, st, args, epi);
+    if (gemm_use_glds4()) hipLaunchKernelGGL((gemm_bf16_glds4_kernel<Epi>), dim3((unsigned)total), dim3(256), 2 * kG2SmemGlds, st, args, epi);
+    else hipLaunchKernelGGL((gemm_bf16_glds_kernel<Epi>), dim3((unsigned)total), dim3(256), kG2SmemGlds, st, args, epi);
   }
   MI_LAUNCH_CHECK(what);
   return MI_OK;
@@ -1229,31 +1372,24 @@ __device__ __forceinline__ void dup_flags_block(const DupFlagJob& J, int a, int 
 }
 // 64 x 64 tiles, 16-byte loads and 8-byte stores in both orientations (R % 4 == 0 and C % 4 == 0; 16-byte aligned
 // bases): 34 MB move per bilinear forward, ~10 us with 4-byte accesses on 32 x 32 tiles.
-static __global__ __launch_bounds__(256) void cvt_transpose3_kernel(CvtJobs jobs) {
-  kernarg_prefetch<(int)sizeof(CvtJobs)>();
-  __shared__ float tile[64][65];
-  if (blockIdx.z == 4) {  // the equal-id flags ride along: (row block, 64 column blocks) pairs over this slice's blocks
-    const DupFlagJob& D = jobs.dup;
-    const int chunks = (D.nb + 63) / 64, total = D.na * chunks;
-    for (int w = (int)(blockIdx.y * gridDim.x + blockIdx.x); w < total; w += (int)(gridDim.x * gridDim.y)) {
-      dup_flags_block(D, w / chunks, (w % chunks) * 64, reinterpret_cast<int64_t*>(&tile[0][0]));
-      __syncthreads();
-    }
-    return;
-  }
-  const CvtJob& J = jobs.j[blockIdx.z];
-  const int64_t r0 = (int64_t)blockIdx.y * 64, c0 = (int64_t)blockIdx.x * 64;
+__device__ __forceinline__ void cvt_tile_block(const CvtJob& J, int bx, int by, float (*tile)[65]) {
+  const int64_t r0 = (int64_t)by * 64, c0 = (int64_t)bx * 64;
   if (r0 >= J.R || c0 >= J.C) return;
   const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;  // 16 column quads x 16 rows per pass
+  f32x4 vq[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {  // all four loads in flight before the first use
+    const int64_t r = r0 + ty + 16 * q, c = c0 + 4 * tx;
+    vq[q] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    if (r < J.R && c < J.C) vq[q] = *reinterpret_cast<const f32x4*>(J.in + r * J.C + c);
+  }
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const int rl = ty + 16 * q;
     const int64_t r = r0 + rl, c = c0 + 4 * tx;
-    f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
-    if (r < J.R && c < J.C) {
-      v = *reinterpret_cast<const f32x4*>(J.in + r * J.C + c);
+    f32x4 v = vq[q];
+    if (r < J.R && c < J.C)
       for (int sl = 1; sl < J.n_slab; ++sl) v += *reinterpret_cast<const f32x4*>(J.in + sl * J.slab_stride + r * J.C + c);
-    }
 #pragma unroll
     for (int e = 0; e < 4; ++e) tile[rl][4 * tx + e] = v[e];
     if ((J.out_rm || J.out_frag) && r < J.R && c < J.C) {
@@ -1274,6 +1410,20 @@ static __global__ __launch_bounds__(256) void cvt_transpose3_kernel(CvtJobs jobs
       *reinterpret_cast<bf16x4*>(J.out_t + c * J.R + r) = o;
     }
   }
+}
+static __global__ __launch_bounds__(256) void cvt_transpose3_kernel(CvtJobs jobs) {
+  kernarg_prefetch<(int)sizeof(CvtJobs)>();
+  __shared__ float tile[64][65];
+  if (blockIdx.z == 4) {  // the equal-id flags ride along: (row block, 64 column blocks) pairs over this slice's blocks
+    const DupFlagJob& D = jobs.dup;
+    const int chunks = (D.nb + 63) / 64, total = D.na * chunks;
+    for (int w = (int)(blockIdx.y * gridDim.x + blockIdx.x); w < total; w += (int)(gridDim.x * gridDim.y)) {
+      dup_flags_block(D, w / chunks, (w % chunks) * 64, reinterpret_cast<int64_t*>(&tile[0][0]));
+      __syncthreads();
+    }
+    return;
+  }
+  cvt_tile_block(jobs.j[blockIdx.z], (int)blockIdx.x, (int)blockIdx.y, tile);
 }
 // any shape: 32 x 32 tiles, element accesses
 static __global__ __launch_bounds__(256) void cvt_transpose3_generic_kernel(CvtJobs jobs) {
@@ -1322,6 +1472,163 @@ static inline int launch_cvt_transpose3(const CvtJobs& jobs, hipStream_t st, con
       dim3 grid((unsigned)((cmax + 31) / 32), (unsigned)((rmax + 31) / 32), 4);
       hipLaunchKernelGGL(cvt_transpose3_generic_kernel, grid, dim3(256), 0, st, jobs);
     }
+  }
+  MI_LAUNCH_CHECK(what);
+  return MI_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ prep + T, one launch
+// The bilinear forward used to open with two short launches, the second waiting for the first: the fp32 -> bf16
+// conversions (9 us) and T = X W on 128 tiles (10 us with half the chip idle); a launch of this size costs ~4 us in
+// ramp and drain alone.  Here both are ONE grid: blocks [0, n_t) compute a 128 x 128 tile of T straight from the fp32
+// operands (converted on the way into LDS: X as it lies, W transposed by loading it with the lanes along n, so both LDS
+// images are K-contiguous with the 144-byte pitch of gemm_bf16_kernel), all other blocks do the conversions nobody in
+// this launch depends on (X^T and W for the backward's products, Y row-major and fragment-major, the equal-id flags) on
+// the CUs the tiles leave free.  T is rounded exactly as before: bf16 operands, fp32 accumulation, one rounding to bf16.
+struct PrepTArgs {
+  const float* x;    // [m][k]
+  const float* w;    // [k][n]
+  int64_t m, n, k;   // k % 64 == 0, n % 128 == 0
+  bf16_t* tb;        // [m][n]
+  bf16_t* tfb;       // fragment-major copy (EpiOut::bf_frag) or null
+  int n_t;           // tiles of T
+  int job_begin[6];  // conversion blocks (counted from n_t): first block of job q; [4] = flags, [5] = end
+  int job_nx[4];     // 64-column tiles per tile row of job q
+  CvtJobs jobs;
+};
+constexpr size_t kPrepTSmem = 2 * 2 * kTile * kG2LD * sizeof(bf16_t);  // 73,728 bytes (>= the conversion tile, 16,640)
+
+static __global__ __launch_bounds__(256, 2) void bilinear_prep_t_kernel(PrepTArgs a) {
+  kernarg_prefetch<(int)sizeof(PrepTArgs)>();
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  const int blk = (int)blockIdx.x;
+  if (blk >= a.n_t) {  // ---- conversion roles
+    float(*tile)[65] = reinterpret_cast<float(*)[65]>(smem_raw);
+    const int c = blk - a.n_t;
+    if (c >= a.job_begin[4]) {
+      const DupFlagJob& D = a.jobs.dup;
+      const int chunks = (D.nb + 63) / 64, w = c - a.job_begin[4];
+      if (w < D.na * chunks) dup_flags_block(D, w / chunks, (w % chunks) * 64, reinterpret_cast<int64_t*>(smem_raw));
+      return;
+    }
+    int q = 0;
+    while (q < 3 && c >= a.job_begin[q + 1]) ++q;
+    const int t = c - a.job_begin[q];
+    cvt_tile_block(a.jobs.j[q], t % a.job_nx[q], t / a.job_nx[q], tile);
+    return;
+  }
+  // ---- a tile of T
+  bf16_t* As = reinterpret_cast<bf16_t*>(smem_raw);  // [2][128 rows][72]
+  bf16_t* Bs = As + 2 * kTile * kG2LD;               // [2][128 n][72]
+  const int nbx = (int)(a.n / kTile);
+  const int64_t m0 = (int64_t)(blk / nbx) * kTile, n0 = (int64_t)(blk % nbx) * kTile;
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int r32 = lane & 31, half = lane >> 5;
+  const int xr = tid >> 4, xc = tid & 15;   // X staging: rows xr + 16 q, float4 number xc of the 64-wide k slice
+  const int wnl = tid & 127, wk = tid >> 7;  // W staging: column wnl, k rows 32 wk .. 32 wk + 31 of the slice
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+  f32x4 rx[8];
+  float rw[32];
+  const float* xp[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    int64_t row = m0 + xr + 16 * q;
+    if (row >= a.m) row = a.m - 1;  // clamped rows only feed outputs the epilogue drops
+    xp[q] = a.x + row * a.k + 4 * xc;
+  }
+  const float* wp = a.w + (int64_t)(32 * wk) * a.n + n0 + wnl;
+  auto load_tile = [&](int64_t k0) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) rx[q] = *reinterpret_cast<const f32x4*>(xp[q] + k0);
+#pragma unroll
+    for (int j = 0; j < 32; ++j) rw[j] = wp[(k0 + j) * a.n];
+  };
+  auto store_tile = [&](int buf) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const bf16x4 o = {(bf16_t)rx[q][0], (bf16_t)rx[q][1], (bf16_t)rx[q][2], (bf16_t)rx[q][3]};
+      *reinterpret_cast<bf16x4*>(&As[(buf * kTile + xr + 16 * q) * kG2LD + 4 * xc]) = o;
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      bf16x8 o;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = (bf16_t)rw[8 * e + j];
+      *reinterpret_cast<bf16x8*>(&Bs[(buf * kTile + wnl) * kG2LD + 32 * wk + 8 * e]) = o;
+    }
+  };
+
+  const int nt = (int)(a.k / kG2KT);
+  load_tile(0);
+  store_tile(0);
+  __syncthreads();
+  for (int t = 0; t < nt; ++t) {
+    const int buf = t & 1;
+    const bool more = t + 1 < nt;
+    if (more) load_tile((int64_t)(t + 1) * kG2KT);
+    const bf16_t* at = As + buf * kTile * kG2LD;
+    const bf16_t* bt = Bs + buf * kTile * kG2LD;
+#pragma unroll
+    for (int kk = 0; kk < kG2KT / 16; ++kk) {
+      bf16x8 af[2], bfr[2];
+#pragma unroll
+      for (int tm = 0; tm < 2; ++tm)
+        af[tm] = *reinterpret_cast<const bf16x8*>(&at[(wm * 64 + tm * 32 + r32) * kG2LD + kk * 16 + 8 * half]);
+#pragma unroll
+      for (int tn = 0; tn < 2; ++tn)
+        bfr[tn] = *reinterpret_cast<const bf16x8*>(&bt[(wn * 64 + tn * 32 + r32) * kG2LD + kk * 16 + 8 * half]);
+#pragma unroll
+      for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn)
+          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[tm], bfr[tn], acc[tm][tn], 0, 0, 0);
+    }
+    if (more) store_tile(buf ^ 1);
+    __syncthreads();
+  }
+  wave_tile_store_bf16(acc, smem_raw + wave * kEpiLdsPerWave, a.tb, a.n, nullptr, 0, m0 + wm * 64, n0 + wn * 64, a.m, a.n,
+                       a.tfb);
+}
+
+// conversions: up to four CvtJob (64 x 64 tiles each) + the flag job; returns MI_EINVAL for shapes the fused kernel does
+// not take (the caller then runs the conversion launch and the plain GEMM)
+static inline int launch_prep_t(const float* x, const float* w, int64_t m, int64_t n, int64_t k, bf16_t* tb, bf16_t* tfb,
+                                const CvtJobs& jobs, hipStream_t st, const char* what) {
+  static const bool off = getenv("MI_NO_PREP_T") != nullptr;  // A/B switch: separate conversion and GEMM launches
+  if (off || k % 64 != 0 || n % kTile != 0 || m < 1 || (uintptr_t)x % 16 != 0 || (uintptr_t)w % 4 != 0 ||
+      (uintptr_t)tb % 16 != 0 || (tfb && (m % 32 != 0 || (uintptr_t)tfb % 16 != 0)))
+    return MI_EINVAL;
+  PrepTArgs a{};
+  a.x = x; a.w = w; a.m = m; a.n = n; a.k = k; a.tb = tb; a.tfb = tfb;
+  a.n_t = (int)(((m + kTile - 1) / kTile) * (n / kTile));
+  a.jobs = jobs;
+  int total = 0;
+  for (int q = 0; q < 4; ++q) {
+    const CvtJob& J = jobs.j[q];
+    if (J.R > 0 && (J.R % 4 != 0 || J.C % 4 != 0 || (uintptr_t)J.in % 16 != 0 || (uintptr_t)J.out_rm % 8 != 0 ||
+                    (uintptr_t)J.out_t % 8 != 0 || J.n_slab > 1 || (J.out_frag && (J.R % 32 != 0 || J.C % 16 != 0))))
+      return MI_EINVAL;
+    a.job_begin[q] = total;
+    a.job_nx[q] = J.R > 0 ? (int)((J.C + 63) / 64) : 1;
+    if (J.R > 0) total += a.job_nx[q] * (int)((J.R + 63) / 64);
+  }
+  a.job_begin[4] = total;
+  if (jobs.dup.na > 0) total += jobs.dup.na * ((jobs.dup.nb + 63) / 64);
+  a.job_begin[5] = total;
+  MI_SET_DYN_SMEM(bilinear_prep_t_kernel, kPrepTSmem, "hipFuncSetAttribute(bilinear_prep_t_kernel)");
+  {
+    ProfScope prof_(what, st);
+    hipLaunchKernelGGL(bilinear_prep_t_kernel, dim3((unsigned)(a.n_t + total)), dim3(256), kPrepTSmem, st, a);
   }
   MI_LAUNCH_CHECK(what);
   return MI_OK;

@@ -317,6 +317,87 @@ def _concat_matrix_step_blocked(x, y, study_id, params, estimator, rb, round_fn=
     return {"scores": s_all, "loss": loss, "dx": xl.grad, "dy": yl.grad, "dparams": [p.grad for p in pl]}
 
 
+def concat_step_rounded(x, y, study_id, params, estimator: str, row_block: int = 64, round_fn=None):
+    """fp64 forward + backward of the factorised concat-MLP critic with ALL rounding points of the 16-bit MFMA path
+    (csrc/mi_concat_fwd_dma.h, csrc/mi_concat_bwd.h), the backward in closed form instead of autograd:
+
+      forward   H1 = bf16(relu(U_i + V_j)), W2 -> bf16 (as ``concat_scores_matrix(round_fn=...)``);
+      dU / dV   E[p, k] = sum_n M[p, n] bf16(w3[n] W2[n, k])               (prep_w2w_kernel rounds the PRODUCT)
+      dW2 ...   D[n, k] = sum_p M[p, n] bf16(g_p relu(U_i[k] + V_j[k]))    (concat_bwd_dw2_kernel rounds the PRODUCT)
+      everything else (first layer, bound, g, the finishing sums) exact.
+
+    With round_fn = identity this equals ``concat_matrix_step`` (checked in tests/test_oracle_golden.py), which pins the
+    closed form; with round_fn = round_bf16 (default) it is what the bf16 kernels compute up to fp32 accumulation order.
+    Rows are processed ``row_block`` at a time ([rb, B, h1] fp64 temporaries)."""
+    rf = round_bf16 if round_fn is None else round_fn
+    w1, b1, w2, b2, w3, b3 = [p.detach() for p in params]
+    x, y = x.detach(), y.detach()
+    b, dx = x.shape
+    w3v = w3.reshape(-1)
+    u = F.linear(x, w1[:, :dx])
+    v = F.linear(y, w1[:, dx:], b1)
+    w2r = rf(w2)
+    w2w = rf(w2 * w3v[:, None])  # [h2, h1]
+
+    def block(s):
+        pre = u[s:s + row_block, None, :] + v[None, :, :]
+        h1 = F.relu(pre)
+        z2 = F.linear(rf(h1), w2r, b2)
+        return pre, h1, z2
+
+    s_all = torch.cat([F.linear(F.relu(block(s)[2]), w3, b3).squeeze(-1) for s in range(0, b, row_block)], 0)
+    loss = bound_from_matrix(s_all, study_id, estimator)
+    g = matrix_grad_scores(s_all, study_id)
+    du = torch.zeros_like(u)
+    dv = torch.zeros_like(v)
+    dmat = torch.zeros_like(w2)
+    mvec = torch.zeros_like(b2)
+    for s in range(0, b, row_block):
+        pre, h1, z2 = block(s)
+        gb = g[s:s + row_block, :, None]
+        m = (z2 > 0).to(x.dtype)
+        dh1 = gb * (pre > 0).to(x.dtype) * (m @ w2w)
+        du[s:s + row_block] = dh1.sum(1)
+        dv += dh1.sum(0)
+        hf = rf(h1 * gb)
+        dmat += torch.einsum("ijn,ijk->nk", m, hf)
+        mvec += (gb * m).sum((0, 1))
+    dparams = [torch.cat([du.t() @ x, dv.t() @ y], 1), dv.sum(0), w3v[:, None] * dmat, w3v * mvec,
+               ((w2 * dmat).sum(1) + b2 * mvec).reshape(w3.shape), g.sum().reshape(b3.shape)]
+    return {"scores": s_all, "loss": loss, "dx": du @ w1[:, :dx], "dy": dv @ w1[:, dx:], "dparams": dparams}
+
+
+def concat_relu_flip_budget(x, y, params, margin: float, round_fn=None):
+    """How far can the choice of relu'(0) move the gradients?  A second-layer pre-activation within the forward's own
+    rounding noise of zero comes out on either side in two correct implementations (the 16-bit path rounds H1 to bf16:
+    an fp32 and an fp64 first layer round a few H1 elements to neighbouring bf16 values, which moves Z2 by up to
+    ulp(H1) * |W2| ~ 1e-4), and its sign bit M switches a whole term of the backward on or off.  For the POSITIVE pairs
+    (weight 1/B each; a negative pair weighs ~1/B^2 and is invisible at the test tolerances) this returns elementwise
+    bounds on the movement of dx, dy, dW2 and db2 if every unit n of pair (i, i) with |Z2| < ``margin`` flipped:
+
+        dU_i[k] moves by g_ii A[i, k] w3[n] W2[n, k]  ->  dx row i, dy row i through W1
+        D[n, k] moves by g_ii H1[i, k]                ->  dW2 row n;   db2[n] by g_ii w3[n]        (g_ii = -1/B)
+
+    Test infrastructure: the tests add these budgets to their absolute tolerance and print how many units are affected."""
+    rf = (lambda t: t) if round_fn is None else round_fn
+    w1, b1, w2, b2, w3, _ = [p.detach() for p in params]
+    b, dx = x.shape
+    w3v = w3.reshape(-1)
+    pre = F.linear(x, w1[:, :dx]) + F.linear(y, w1[:, dx:], b1)  # pair (i, i)
+    h1 = F.relu(pre)
+    z2 = F.linear(rf(h1), rf(w2), b2)
+    amb = z2.abs() < margin                                     # [B, h2]
+    w2w = w2 * w3v[:, None]                                     # [h2, h1]
+    bdx, bdy = torch.zeros_like(x), torch.zeros_like(y)
+    for i, n in torch.nonzero(amb).tolist():                    # one exact movement vector per candidate flip
+        du = (pre[i] > 0).to(x.dtype) * w2w[n] / b
+        bdx[i] += (du @ w1[:, :dx]).abs()
+        bdy[i] += (du @ w1[:, dx:]).abs()
+    ambf = amb.to(x.dtype)
+    return {"n_units": int(amb.sum()), "dx": bdx, "dy": bdy, "dw2": w3v.abs()[:, None] * (ambf.t() @ h1) / b,
+            "db2": w3v.abs() * ambf.sum(0) / b}
+
+
 # ----------------------------------------------------------------------------------------------------
 # closed-form backward of the factorised concat-MLP critic (SURVEY.md A.2) -- used to check autograd-free
 # ----------------------------------------------------------------------------------------------------

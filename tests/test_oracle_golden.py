@@ -157,6 +157,23 @@ def test_matrix_grad_closed_form():
     np.testing.assert_allclose(s.grad.numpy(), orc.matrix_grad_scores(s.detach(), sid).numpy(), atol=1e-15)
 
 
+@pytest.mark.parametrize("est", ["dv", "infonce"])
+def test_concat_closed_form_backward_equals_autograd(est):
+    """``concat_step_rounded`` (the checker of the bf16 concat-MLP kernels) states the backward in closed form; with the
+    identity as rounding function it must reproduce autograd through the same forward to fp64 rounding."""
+    x, y, sid, params = orc.synthetic_case(48, 24, 40, h1=64, h2=32, salt=3, dup=True, dtype=torch.float64)
+    a = orc.concat_matrix_step(x, y, sid, params, est)
+    c = orc.concat_step_rounded(x, y, sid, params, est, row_block=16, round_fn=lambda t: t)
+    np.testing.assert_allclose(c["loss"].numpy(), a["loss"].numpy(), atol=1e-13)
+    for got, ref in zip([c["dx"], c["dy"], *c["dparams"]], [a["dx"], a["dy"], *a["dparams"]]):
+        np.testing.assert_allclose(got.reshape(ref.shape).numpy(), ref.numpy(), atol=1e-13 * max(1.0, float(ref.abs().max())),
+                                   rtol=1e-10)
+    # and the rounded variant stays in its neighbourhood (bf16 operands move these heavily cancelling gradients by tens
+    # of percent of max|grad|, DESIGN.md section 2; a sign or index error would move them by > 100 %)
+    r = orc.concat_step_rounded(x, y, sid, params, est, row_block=16)
+    assert float((r["dx"] - a["dx"]).abs().max()) < 0.5 * float(a["dx"].abs().max())
+
+
 def test_invariants_a4():
     """dv = infonce - log N_neg; constant shift invariance; duplicate ids drop two pairs."""
     x, y, sid, params = orc.synthetic_case(10, 16, 16, salt=5, dtype=torch.float64)

@@ -156,11 +156,22 @@ def test_concat_all_gradients_at_size(dev, b, d, h1, h2, rb, precision):
     sid = _dup_ids(b)
     loss, grads = _concat_all_grads(dev, x, y, sid, params, (h1, h2), "dv", precision)
     p64 = [p.double() for p in params]
-    rf = orc.round_bf16 if precision == "bf16" else None
-    o = orc.concat_matrix_step(x.double(), y.double(), sid, p64, "dv", round_fn=rf, row_block=rb)
+    budget = {}
+    if precision == "bf16":
+        # the oracle that rounds where the forward AND the backward kernels round (closed-form backward) ...
+        o = orc.concat_step_rounded(x.double(), y.double(), sid, p64, "dv", row_block=rb)
+        # ... plus what the convention for relu'(0) may move: at B = 512, h = 1024 / 512 two of the 262,144 (positive
+        # pair, unit) pre-activations land within the forward's rounding noise of zero, and one such sign moves a dx row
+        # by 10 % of max|dx| (found with tools/diag/concat_bf16_debug.py).  margin = one bf16 ulp of H1 times max|W2|.
+        margin = 2.0 ** -8 * 2.0 * float(p64[2].abs().max())
+        budget = orc.concat_relu_flip_budget(x.double(), y.double(), p64, margin, round_fn=orc.round_bf16)
+        print("units of positive pairs within", margin, "of zero:", budget["n_units"])
+    else:
+        o = orc.concat_matrix_step(x.double(), y.double(), sid, p64, "dv", row_block=rb)
     sc = max(float(o["scores"].abs().max()), 1.0)
     assert abs(float(loss) - float(o["loss"])) < (3e-5 + 1e-5 * abs(float(o["loss"])) if precision == "f32" else 3e-3 * sc)
     refs = [o["dx"], o["dy"]] + list(o["dparams"])
+    errs = {}
     for name, got, ref in zip(GRAD_NAMES, grads, refs):
         ref = ref.reshape(got.shape)
         scale = 1.0 if name == "db3" else float(ref.abs().max())
@@ -170,5 +181,11 @@ def test_concat_all_gradients_at_size(dev, b, d, h1, h2, rb, precision):
             np.testing.assert_allclose(got.numpy(), ref.numpy(), rtol=2e-3, atol=(1e-5 if name == "db3" else 5e-4) * scale,
                                        err_msg=name)
         else:
-            err = float((got.double() - ref).abs().max()) / scale
-            assert err < (2e-5 if name == "db3" else 2e-2), (name, err)
+            slack = budget.get(name)
+            err = (got.double() - ref).abs()
+            if slack is not None:
+                err = (err - slack.reshape(got.shape)).clamp_min(0.0)
+            errs[name] = float(err.max()) / scale
+    print("bf16 concat errors vs the rounded oracle:", {k: f"{v:.2e}" for k, v in errs.items()})
+    for name, err in errs.items():
+        assert err < (2e-5 if name == "db3" else 2e-2), (name, err, errs)
