@@ -39,7 +39,9 @@ for _p in (ROOT, PKG):
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
-PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}  # dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md
+PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3,  # dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md
+               "bf16x3": 2500.0 / 3,     # three bf16 MFMAs per algorithmic product
+               "fp8": 2500.0}            # non-scaled fp8 MFMA runs at the bf16 rate; the backward is bf16
 PEAK_HBM_GBS = 8000.0
 
 
@@ -52,7 +54,7 @@ def parse_args():
     p.add_argument("--dim", type=int, default=512)
     p.add_argument("--critic", default="bilinear", choices=["bilinear", "concat_mlp"])
     p.add_argument("--estimator", default="infonce", choices=["dv", "infonce"])
-    p.add_argument("--precision", default="bf16", choices=["bf16", "f32"])
+    p.add_argument("--precision", default="bf16", choices=["bf16", "f32", "bf16x3", "fp8"])
     p.add_argument("--graph", default="auto", choices=["auto", "on", "off"],
                    help="on: replay the step from a hipGraph (one GPU: GraphedMiStep; N GPUs: the two compute sections "
                         "are graphs, the RCCL collectives stay eager between them).  off: the same C-ABI calls issued one "
@@ -61,6 +63,7 @@ def parse_args():
     p.add_argument("--no-secondary", action="store_true")
     p.add_argument("--secondary-steps", type=int, default=5)
     p.add_argument("--no-parity-mode", action="store_true")
+    p.add_argument("--no-fp8", action="store_true")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-seconds", type=float, default=15.0)
     p.add_argument("--profile-steps", type=int, default=5)
@@ -127,12 +130,13 @@ def kernel_flops(name, br, b, d_img, d_txt, h1=1024, h2=512):
 class Stepper:
     """One critic forward + backward through the product API (no autograd anywhere in the timed path)."""
 
-    def __init__(self, kind, args, rank, world, device, group, precision=None, graph=True):
+    def __init__(self, kind, args, rank, world, device, group, precision=None, graph=True, batch=None, dim=None):
         from mutual_info_img_txt.graphed import GraphedMiStep
         self.kind, self.world, self.device = kind, world, device
-        d = args.dim
+        d = dim or args.dim
+        batch = batch or args.batch
         precision = precision or args.precision
-        x, y, sid = make_inputs(args.batch, d, d, 3, rank, world, device)
+        x, y, sid = make_inputs(batch, d, d, 3, rank, world, device)
         self.critic = make_critic(kind, d, d, 3, device)
         self.dist_mode = world > 1 or bool(os.environ.get("MI_BENCH_FORCE_DIST"))
         self.graph_used = bool(graph)
@@ -148,7 +152,7 @@ class Stepper:
                                                  critic=kind, group=group, capture=bool(graph))
             self.eager_obj = self.step_obj if not graph else None
         else:
-            self.step_obj = GraphedMiStep(self.critic, args.batch, d, d, args.estimator, precision, device, capture=bool(graph))
+            self.step_obj = GraphedMiStep(self.critic, batch, d, d, args.estimator, precision, device, capture=bool(graph))
             self.step_obj.set_inputs(x, y, sid)
             self.eager_obj = self.step_obj
 
@@ -372,8 +376,8 @@ def main():
     want_graph = args.graph in ("on", "auto")
     b, d, br = args.batch, args.dim, args.batch // world
 
-    def run(kind, steps, warmup, precision=None, timed_iters=0):
-        st = Stepper(kind, args, rank, world, device, group, precision=precision, graph=want_graph)
+    def run(kind, steps, warmup, precision=None, timed_iters=0, batch=None, dim=None):
+        st = Stepper(kind, args, rank, world, device, group, precision=precision, graph=want_graph, batch=batch, dim=dim)
         if args.graph == "auto":
             st.choose_launch_mode(world)
         elapsed = timed_run(st, steps, warmup, world)
@@ -415,17 +419,41 @@ def main():
     torch.cuda.empty_cache()
     if not args.no_parity_mode and args.precision != "f32":
         # the same step in the mode whose results match the fp32 reference
+        out["parity_mode"] = {}
+        notes = {"f32": "v_mfma_f32_32x32x2_f32: exact fp32 products, the mode tests/ holds to the fp32 tolerances of "
+                        "DESIGN.md section 2",
+                 "bf16x3": "two-part bf16 operands, three bf16 MFMAs per product (K tripled), fp32 accumulate: held to the "
+                           "same fp32 tolerances (tests/test_parity_configs.py); bilinear critic only"}
+        for mode in (["f32", "bf16x3"] if args.critic == "bilinear" and world == 1 else ["f32"]):
+            try:
+                n2 = max(3, args.steps // 10)
+                st2, el2, k2, _ = run(args.critic, n2, 2, precision=mode)
+                ms2 = el2 / n2 * 1e3
+                out["parity_mode"][mode] = {
+                    "ms_per_step": round(ms2, 4), "value": round(b / (ms2 * 1e-3), 1), "unit": "pairs/s",
+                    "step_frac_of_peak": round(flops / (ms2 * 1e-3) / 1e12 / (PEAK_TFLOPS[mode] * world), 5),
+                    "peak": round(PEAK_TFLOPS[mode], 1), "loss": st2.loss(), "note": notes[mode]}
+                del st2
+            except Exception as e:
+                out["parity_mode"][mode] = {"error": f"{type(e).__name__}: {e}"}
+            torch.cuda.empty_cache()
+        torch.cuda.empty_cache()
+    if not args.no_fp8 and args.critic == "bilinear" and world == 1:
+        # BASELINE configs[4] on ONE GPU (the whole 8192 x 8192 score matrix, not a rank's 1024-row share)
         try:
-            st2, el2, k2, _ = run(args.critic, max(3, args.steps // 10), 2, precision="f32")
-            ms2 = el2 / max(3, args.steps // 10) * 1e3
-            out["parity_mode"] = {"f32": {"ms_per_step": round(ms2, 4), "value": round(b / (ms2 * 1e-3), 1), "unit": "pairs/s",
-                                          "step_frac_of_peak": round(flops / (ms2 * 1e-3) / 1e12 / (PEAK_TFLOPS["f32"] * world), 5),
-                                          "peak": PEAK_TFLOPS["f32"], "loss": st2.loss(),
-                                          "note": "v_mfma_f32_32x32x2_f32: exact fp32 products, the mode tests/ holds to the "
-                                                  "fp32 tolerances of DESIGN.md section 2"}}
-            del st2
+            b8, d8, n8 = 8192, 1024, max(3, args.steps // 10)
+            st4, el4, k4, _ = run("bilinear", n8, 2, precision="fp8", batch=b8, dim=d8)
+            ms4 = el4 / n8 * 1e3
+            fl4 = algorithmic_flops("bilinear", b8, d8, d8)
+            out["fp8_mode"] = {
+                "workload": f"BASELINE configs[4] on one GPU: fp8 (e4m3, per-tensor scale absmax / 448) bilinear critic "
+                            f"fwd+bwd, B={b8}, d={d8}; forward products on v_mfma_f32_32x32x16_fp8_fp8, backward on bf16 MFMA",
+                "value": round(b8 / (ms4 * 1e-3), 1), "unit": "pairs/s", "ms_per_step": round(ms4, 4), "steps": n8,
+                "loss": st4.loss(), "step_algorithmic_tflops": round(fl4 / (ms4 * 1e-3) / 1e12, 2),
+                "kernels_us": {k: round(v["ms_avg"] * 1e3, 2) for k, v in sorted(k4.items(), key=lambda kv: -kv[1]["ms_total"])}}
+            del st4
         except Exception as e:
-            out["parity_mode"] = {"error": f"{type(e).__name__}: {e}"}
+            out["fp8_mode"] = {"error": f"{type(e).__name__}: {e}"}
         torch.cuda.empty_cache()
     if not args.no_secondary:
         other = "concat_mlp" if args.critic == "bilinear" else "bilinear"

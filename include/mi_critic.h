@@ -35,7 +35,14 @@
  *
  * estimator: MI_DV = 0 (loss = LSE(neg) - log N_neg - mean(pos)), MI_INFONCE = 1 (no log N_neg term).
  * precision: MI_PREC_F32 = 0 (fp32-input MFMA, exact fp32 products, parity mode),
- *            MI_PREC_BF16 = 1 (bf16 MFMA operands, fp32 accumulate).
+ *            MI_PREC_BF16 = 1 (bf16 MFMA operands, fp32 accumulate),
+ *            MI_PREC_BF16X3 = 2 (bilinear critic with a weight matrix only: every operand split into two bf16 parts,
+ *            three bf16 MFMAs per product, fp32 accumulate -- products good to ~2^-16 at a third of the bf16 rate; the
+ *            separable critic runs its fp32 path under this code, the concat-MLP entry points reject it),
+ *            MI_PREC_FP8 = 3 (bilinear critic with a weight matrix only; widths multiples of 16: x, y, W and T = x W are
+ *            quantised to OCP e4m3 with per-tensor scales absmax / 448 computed on the device, both forward products
+ *            run on the fp8 MFMA with fp32 accumulation, the backward is straight-through on the quantised values
+ *            with bf16 MFMA operands; other entry points reject it).
  */
 #ifndef MI_CRITIC_H
 #define MI_CRITIC_H
@@ -58,6 +65,8 @@ extern "C" {
 
 #define MI_PREC_F32 0
 #define MI_PREC_BF16 1
+#define MI_PREC_BF16X3 2
+#define MI_PREC_FP8 3
 
 /* Statistics block written by every forward call and read by the matching backward call (64 bytes). */
 typedef struct mi_stats {

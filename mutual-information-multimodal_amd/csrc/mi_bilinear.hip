@@ -16,6 +16,7 @@
 #include "mi_gemm.h"
 #include "mi_gemm_bf16.h"
 #include "mi_bilinear_flash.h"
+#include "mi_fp8.h"
 
 namespace mi {
 
@@ -41,11 +42,22 @@ struct BilinearPlan {
   Partial* fl_rec[2];
   unsigned char* fl_dup[2];  // equal-id flags per 32 x 32 block: [br / 32][b / 32] and its transpose
   bf16_t *tfb, *yfb;         // fragment-major copies of T and Y: the stationary operands of the fused kernel
+  // bf16x3 (MI_PREC_BF16X3): every bf16 operand copy holds hi and lo parts along a tripled K (mi_gemm_bf16.h,
+  // split3_offsets); A-side role: xb, xtb, tb, gb, gtb, dtb; B-side role: yb, ytb, wb, wtb, ttb, dttb
+  int x3;  // 3 in that mode, else 1
+  // fp8 mode (MI_PREC_FP8, mi_fp8.h): e4m3 copies of the operands of the two forward products and the scale block; the
+  // bf16 copies of the quantised values for the backward live in xtb, ytb, wb, ttb
+  fp8_t *qx8, *qy8, *qwt8, *qt8;
+  Fp8Scales* f8sc;
   size_t bytes;
 };
 
+static bool fp8_ok(int64_t br, int64_t b, int64_t dx, int64_t dy, int precision, bool has_w) {
+  return precision == MI_PREC_FP8 && has_w && br % 8 == 0 && b % 8 == 0 && dx % 16 == 0 && dy % 16 == 0;
+}
 static bool fast_ok(int64_t br, int64_t b, int64_t dx, int64_t dy, int precision, bool has_w) {
-  return precision == MI_PREC_BF16 && has_w && br % 8 == 0 && b % 8 == 0 && dx % 8 == 0 && dy % 8 == 0;
+  return (precision == MI_PREC_BF16 || precision == MI_PREC_BF16X3) && has_w && br % 8 == 0 && b % 8 == 0 &&
+         dx % 8 == 0 && dy % 8 == 0;
 }
 
 static BilinearPlan plan_bilinear(Workspace& ws, int64_t br, int64_t b, int64_t dx, int64_t dy, int precision) {
@@ -53,15 +65,24 @@ static BilinearPlan plan_bilinear(Workspace& ws, int64_t br, int64_t b, int64_t 
   p.n_partials = ((b + kTile - 1) / kTile) * ((br + kTile - 1) / kTile);
   p.partials = ws.take<Partial>(p.n_partials);
   // forward buffers of the fast path come first so that forward-only callers can pass a smaller workspace
-  p.xb = ws.take<bf16_t>(br * dx);
-  p.xtb = ws.take<bf16_t>(br * dx);
-  p.yb = ws.take<bf16_t>(b * dy);
-  p.ytb = ws.take<bf16_t>(b * dy);
-  p.wb = ws.take<bf16_t>(dx * dy);
-  p.wtb = ws.take<bf16_t>(dx * dy);
-  p.tb = ws.take<bf16_t>(br * dy);
-  p.ttb = ws.take<bf16_t>(br * dy);
+  const int64_t x3 = precision == MI_PREC_BF16X3 ? 3 : 1;
+  p.x3 = (int)x3;
+  p.xb = ws.take<bf16_t>(x3 * br * dx);
+  p.xtb = ws.take<bf16_t>(x3 * br * dx);
+  p.yb = ws.take<bf16_t>(x3 * b * dy);
+  p.ytb = ws.take<bf16_t>(x3 * b * dy);
+  p.wb = ws.take<bf16_t>(x3 * dx * dy);
+  p.wtb = ws.take<bf16_t>(x3 * dx * dy);
+  p.tb = ws.take<bf16_t>(x3 * br * dy);
+  p.ttb = ws.take<bf16_t>(x3 * br * dy);
   p.t = ws.take<float>(br * dy);
+  if (precision == MI_PREC_FP8) {
+    p.qx8 = ws.take<fp8_t>(br * dx);
+    p.qy8 = ws.take<fp8_t>(b * dy);
+    p.qwt8 = ws.take<fp8_t>(dx * dy);
+    p.qt8 = ws.take<fp8_t>(br * dy);
+    p.f8sc = ws.take<Fp8Scales>(1);
+  }
   p.fl = FlashPlan{};
   if (precision == MI_PREC_BF16 && br % 8 == 0 && b % 8 == 0 && dx % 8 == 0) p.fl = flash_plan(br, b, dy);
   for (int q = 0; q < 2; ++q) {
@@ -73,12 +94,12 @@ static BilinearPlan plan_bilinear(Workspace& ws, int64_t br, int64_t b, int64_t 
   p.yfb = p.fl.ok ? ws.take<bf16_t>(b * dy) : nullptr;
   // backward
   p.dt = ws.take<float>(br * dy);
-  if (precision == MI_PREC_BF16) p.g = ws.take<bf16_t>(br * b);
-  else p.g = ws.take<float>(br * b);
+  if (precision == MI_PREC_F32) p.g = ws.take<float>(br * b);
+  else p.g = ws.take<bf16_t>(x3 * br * b);
   p.gb = (bf16_t*)p.g;
-  p.gtb = ws.take<bf16_t>(br * b);
-  p.dtb = ws.take<bf16_t>(br * dy);
-  p.dttb = ws.take<bf16_t>(br * dy);
+  p.gtb = ws.take<bf16_t>(x3 * br * b);
+  p.dtb = ws.take<bf16_t>(x3 * br * dy);
+  p.dttb = ws.take<bf16_t>(x3 * br * dy);
   int64_t tiles = ((dx + kTile - 1) / kTile) * ((dy + kTile - 1) / kTile);
   // split-K so that dW brings ~128 workgroups to the launch it shares with dX (measured at B = 4096, d = 512: 8 splits
   // 16.7 us, 16 splits 19.0 us, 4 splits 19.8 us for the pair)
@@ -131,17 +152,19 @@ static int fast_prep_and_t(const float* x, const float* y, const float* w, const
     const int rc1 = launch_prep_t(x, w, br, dy, dx, p.tb, p.tfb, side, st, "bilinear prep + T = X W");
     if (rc1 != MI_EINVAL) return rc1;
   }
+  const int x3 = p.x3;
+  const int ra = x3 == 3 ? 1 : 0, rb = x3 == 3 ? 2 : 0;  // bf16x3 roles of A-side and B-side operands
   CvtJobs jobs{};
-  jobs.j[0] = CvtJob{x, br, dx, p.xb, p.xtb, 0, 0, nullptr};
-  jobs.j[1] = CvtJob{y, b, dy, p.yb, p.fl.ok ? nullptr : p.ytb, 0, 0, p.fl.ok ? p.yfb : nullptr};
-  jobs.j[2] = CvtJob{w, dx, dy, p.wb, p.wtb, 0, 0, nullptr};
+  jobs.j[0] = CvtJob{x, br, dx, p.xb, p.xtb, 0, 0, nullptr, ra, ra};
+  jobs.j[1] = CvtJob{y, b, dy, p.yb, p.fl.ok ? nullptr : p.ytb, 0, 0, p.fl.ok ? p.yfb : nullptr, rb, rb};
+  jobs.j[2] = CvtJob{w, dx, dy, p.wb, p.wtb, 0, 0, nullptr, rb, rb};
   if (p.fl.ok) jobs.dup = DupFlagJob{sid_rows, sid_cols, (int)(br / 32), (int)(b / 32), p.fl_dup[0], p.fl_dup[1]};
   int rc = launch_cvt_transpose3(jobs, st, "bilinear prep X Y W");
   if (rc) return rc;
   // T[i, c] = sum_a X[i, a] W[a, c]: A = Xb [br][dx], B = W^T [dy][dx]
   EpiStoreMulti e{};
-  e.out[0] = EpiOut{nullptr, 0, 0, p.tb, dy, p.fl.ok ? nullptr : p.ttb, br, p.fl.ok ? p.tfb : nullptr};
-  return launch_gemm_bf16(one_problem(p.xb, dx, p.wtb, dx, br, dy, dx), 1, e, st, "bilinear T = X W");
+  e.out[0] = EpiOut{nullptr, 0, 0, p.tb, dy, p.fl.ok ? nullptr : p.ttb, br, p.fl.ok ? p.tfb : nullptr, ra, rb};
+  return launch_gemm_bf16(one_problem(p.xb, x3 * dx, p.wtb, x3 * dx, br, dy, x3 * dx), 1, e, st, "bilinear T = X W");
 }
 
 static int bilinear_bwd_small(int64_t br, int64_t dx, int64_t dy, float* grad_x, float* grad_w, const BilinearPlan& p,
@@ -179,11 +202,13 @@ static int bilinear_fwd_fast(const float* x, const float* y, const float* w, con
     }
     return launch_finalize(p.fl_rec[0], p.fl.n_rec[0], b, estimator, loss_out, stats, partials_out, st);
   }
-  rc = launch_gemm_bf16(one_problem(p.tb, dy, p.yb, dy, br, b, dy), 1,
+  const int x3 = p.x3;
+  rc = launch_gemm_bf16(one_problem(p.tb, x3 * dy, p.yb, x3 * dy, br, b, x3 * dy), 1,
                         EpiScoreLse2{sid_rows, sid_cols, row_offset, scores_out, p.partials}, st, "bilinear score+LSE");
   if (rc) return rc;
   // the launcher picks 256 x 256 tiles for large score matrices: fewer partials than the plan reserved
-  return launch_finalize(p.partials, gemm_bf16_n_partials(br, b, dy), b, estimator, loss_out, stats, partials_out, st);
+  return launch_finalize(p.partials, gemm_bf16_n_partials(br, b, x3 * dy), b, estimator, loss_out, stats, partials_out,
+                         st);
 }
 
 static int bilinear_bwd_fast(const int64_t* sid_rows, const int64_t* sid_cols, int64_t br, int64_t b, int64_t row_offset,
@@ -205,22 +230,24 @@ static int bilinear_bwd_fast(const int64_t* sid_rows, const int64_t* sid_cols, i
     return bilinear_bwd_small(br, dx, dy, grad_x, grad_w, p, st);
   }
   // G and G^T (bf16) from recomputed score tiles
-  rc = launch_gemm_bf16(one_problem(p.tb, dy, p.yb, dy, br, b, dy), 1,
-                            EpiGradScore2{sid_rows, sid_cols, row_offset, stats, grad_out, p.gb, p.gtb}, st,
+  const int x3 = p.x3;
+  const int ra = x3 == 3 ? 1 : 0, rbk = x3 == 3 ? 2 : 0;
+  rc = launch_gemm_bf16(one_problem(p.tb, x3 * dy, p.yb, x3 * dy, br, b, x3 * dy), 1,
+                            EpiGradScore2{sid_rows, sid_cols, row_offset, stats, grad_out, p.gb, p.gtb, x3 == 3 ? 1 : 0}, st,
                             "bilinear G");
   if (rc) return rc;
   // problem 0: dT[i, c] = sum_j G[i, j] Y[j, c]   (A = G [br][b], B = Y^T [dy][b])  -> bf16 both orientations
   // problem 1: dY[j, c] = sum_i G[i, j] T[i, c]   (A = G^T [b][br], B = T^T [dy][br]) -> fp32 grad_y
   GemmBf16Args two{};
-  two.p[0] = GemmBf16Problem{p.gb, b, p.ytb, b, br, dy, b};
-  two.p[1] = GemmBf16Problem{p.gtb, br, p.ttb, br, b, dy, br};
+  two.p[0] = GemmBf16Problem{p.gb, x3 * b, p.ytb, x3 * b, br, dy, x3 * b};
+  two.p[1] = GemmBf16Problem{p.gtb, x3 * br, p.ttb, x3 * br, b, dy, x3 * br};
   two.n_problems = 2;
-  two.k_chunk = b > br ? b : br;
+  two.k_chunk = x3 * (b > br ? b : br);
   EpiStoreMulti e2{};
-  e2.out[0] = EpiOut{nullptr, 0, 0, p.dtb, dy, p.dttb, br};
+  e2.out[0] = EpiOut{nullptr, 0, 0, p.dtb, dy, p.dttb, br, nullptr, ra, rbk};
   e2.out[1] = EpiOut{grad_y, dy, 0, nullptr, 0, nullptr, 0};
   bool split_done = false;
-  if (p.dt_splits > 1) {
+  if (p.dt_splits > 1 && x3 == 1) {
     // sharded row block: dT partial sums over K chunks into fp32 slabs, beside dY; then one pass that adds the slabs and
     // writes the two bf16 orientations of dT
     EpiStoreMulti es{};
@@ -253,24 +280,121 @@ static int bilinear_bwd_small(int64_t br, int64_t dx, int64_t dy, float* grad_x,
                               hipStream_t st) {
   int rc = MI_OK;
   GemmBf16Args dwx{};
-  dwx.p[0] = GemmBf16Problem{p.xtb, br, p.dttb, br, dx, dy, br};
-  dwx.p[1] = GemmBf16Problem{p.dtb, dy, p.wb, dy, br, dx, dy};
+  const int x3 = p.x3;
+  dwx.p[0] = GemmBf16Problem{p.xtb, x3 * br, p.dttb, x3 * br, dx, dy, x3 * br};
+  dwx.p[1] = GemmBf16Problem{p.dtb, x3 * dy, p.wb, x3 * dy, br, dx, x3 * dy};
   dwx.n_problems = 2;
   EpiStoreMulti e3{};
   e3.out[0] = EpiOut{p.dw_slab, dy, dx * dy, nullptr, 0, nullptr, 0};
   e3.out[1] = EpiOut{grad_x, dx, 0, nullptr, 0, nullptr, 0};
   const int splits[2] = {p.dw_splits, 1};
-  const int64_t chunks[2] = {p.dw_kchunk, dy};
+  const int64_t chunks[2] = {x3 * p.dw_kchunk, x3 * dy};
   rc = launch_gemm_bf16_flat(dwx, splits, chunks, e3, st, "bilinear dW = X^T dT | dX = dT W^T");
   if (rc == MI_EINVAL) {  // shapes the LDS-DMA kernel does not take: one launch each
     EpiStoreMulti e4{};
     e4.out[0] = e3.out[0];
-    rc = launch_gemm_bf16(one_problem(p.xtb, br, p.dttb, br, dx, dy, br, p.dw_kchunk), p.dw_splits, e4, st,
-                          "bilinear dW = X^T dT");
+    rc = launch_gemm_bf16(one_problem(p.xtb, x3 * br, p.dttb, x3 * br, dx, dy, x3 * br, x3 * p.dw_kchunk), p.dw_splits,
+                          e4, st, "bilinear dW = X^T dT");
     if (rc) return rc;
     e4.out[0] = e3.out[1];
-    rc = launch_gemm_bf16(one_problem(p.dtb, dy, p.wb, dy, br, dx, dy), 1, e4, st, "bilinear dX = dT W^T");
+    rc = launch_gemm_bf16(one_problem(p.dtb, x3 * dy, p.wb, x3 * dy, br, dx, x3 * dy), 1, e4, st,
+                          "bilinear dX = dT W^T");
   }
+  if (rc) return rc;
+  return launch_slab_reduce_ld(p.dw_slab, p.dw_splits, dx, dy, grad_w, dy, st, "slab_reduce_ld_kernel");
+}
+
+// ------------------------------------------------------------------------------------------------ fp8 path (mi_fp8.h)
+// absmax -> scales -> e4m3 operands; T on the fp8 MFMA with its absmax in the epilogue; T quantised
+static int fp8_prep_and_t(const float* x, const float* y, const float* w, int64_t br, int64_t b, int64_t dx, int64_t dy,
+                          const BilinearPlan& p, hipStream_t st) {
+  {
+    const hipError_t e = hipMemsetAsync(p.f8sc, 0, sizeof(Fp8Scales), st);
+    if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync(fp8 scales)");
+  }
+  AbsmaxJobs aj{};
+  aj.in[0] = x; aj.n[0] = br * dx; aj.slot[0] = 0;
+  aj.in[1] = y; aj.n[1] = b * dy; aj.slot[1] = 1;
+  aj.in[2] = w; aj.n[2] = dx * dy; aj.slot[2] = 2;
+  aj.sc = p.f8sc;
+  {
+    ProfScope prof_("fp8 absmax X Y W", st);
+    hipLaunchKernelGGL(fp8_absmax_kernel, dim3(128, 3), dim3(256), 0, st, aj);
+  }
+  MI_LAUNCH_CHECK("fp8_absmax_kernel");
+  QuantJobs qj{};
+  qj.j[0] = QuantJob{x, br, dx, 0, p.qx8, nullptr, nullptr, p.xtb};   // A of T = X W; X^T (bf16) for dW
+  qj.j[1] = QuantJob{y, b, dy, 1, p.qy8, nullptr, nullptr, p.ytb};    // B of S = T Y^T; Y^T (bf16) for dT
+  qj.j[2] = QuantJob{w, dx, dy, 2, nullptr, p.qwt8, p.wb, nullptr};   // B of T = X W is W^T; W (bf16) for dX
+  qj.sc = p.f8sc;
+  int64_t rmax = br > b ? br : b, cmax = dx > dy ? dx : dy;
+  if (dx > rmax) rmax = dx;
+  {
+    ProfScope prof_("fp8 quantize X Y W", st);
+    hipLaunchKernelGGL(fp8_quantize_kernel, dim3((unsigned)((cmax + 63) / 64), (unsigned)((rmax + 63) / 64), 3), dim3(256),
+                       0, st, qj);
+  }
+  MI_LAUNCH_CHECK("fp8_quantize_kernel");
+  int rc = launch_gemm_fp8(GemmF8Args{p.qx8, dx, p.qwt8, dx, br, dy, dx}, EpiT8{p.t, p.f8sc}, st, "fp8 T = X W");
+  if (rc) return rc;
+  QuantJobs qt{};
+  qt.j[0] = QuantJob{p.t, br, dy, 3, p.qt8, nullptr, nullptr, p.ttb};  // A of S; T^T (bf16) for dY
+  qt.sc = p.f8sc;
+  {
+    ProfScope prof_("fp8 quantize T", st);
+    hipLaunchKernelGGL(fp8_quantize_kernel, dim3((unsigned)((dy + 63) / 64), (unsigned)((br + 63) / 64), 1), dim3(256), 0, st,
+                       qt);
+  }
+  MI_LAUNCH_CHECK("fp8_quantize_kernel");
+  return MI_OK;
+}
+
+static int bilinear_fwd_fp8(const float* x, const float* y, const float* w, const int64_t* sid_rows, const int64_t* sid_cols,
+                            int64_t br, int64_t b, int64_t row_offset, int64_t dx, int64_t dy, int estimator,
+                            float* loss_out, mi_stats* stats, float* partials_out, float* scores_out,
+                            const BilinearPlan& p, hipStream_t st) {
+  int rc = fp8_prep_and_t(x, y, w, br, b, dx, dy, p, st);
+  if (rc) return rc;
+  EpiScaled<EpiScoreLse2> e{EpiScoreLse2{sid_rows, sid_cols, row_offset, scores_out, p.partials},
+                            {&p.f8sc->scale[3], nullptr}, {&p.f8sc->scale[1], nullptr}};
+  rc = launch_gemm_fp8(GemmF8Args{p.qt8, dy, p.qy8, dy, br, b, dy}, e, st, "fp8 score+LSE");
+  if (rc) return rc;
+  return launch_finalize(p.partials, p.n_partials, b, estimator, loss_out, stats, partials_out, st);
+}
+
+static int bilinear_bwd_fp8(const int64_t* sid_rows, const int64_t* sid_cols, int64_t br, int64_t b, int64_t row_offset,
+                            int64_t dx, int64_t dy, const mi_stats* stats, const float* grad_out, float* grad_x,
+                            float* grad_y, float* grad_w, const BilinearPlan& p, hipStream_t st) {
+  const float* sc = p.f8sc->scale;  // device addresses: x, y, w, T
+  // G and G^T (bf16) from recomputed fp8 score tiles
+  EpiScaled<EpiGradScore2> eg{EpiGradScore2{sid_rows, sid_cols, row_offset, stats, grad_out, p.gb, p.gtb, 0},
+                              {sc + 3, nullptr}, {sc + 1, nullptr}};
+  int rc = launch_gemm_fp8(GemmF8Args{p.qt8, dy, p.qy8, dy, br, b, dy}, eg, st, "fp8 G");
+  if (rc) return rc;
+  // dT = s_y (G y_q) -> bf16 both orientations | dY = s_t (G^T t_q) -> grad_y; operands: the quantised values as bf16
+  GemmBf16Args two{};
+  two.p[0] = GemmBf16Problem{p.gb, b, p.ytb, b, br, dy, b};
+  two.p[1] = GemmBf16Problem{p.gtb, br, p.ttb, br, b, dy, br};
+  two.n_problems = 2;
+  two.k_chunk = b > br ? b : br;
+  EpiScaled<EpiStoreMulti> e2{};
+  e2.inner.out[0] = EpiOut{nullptr, 0, 0, p.dtb, dy, p.dttb, br};
+  e2.inner.out[1] = EpiOut{grad_y, dy, 0, nullptr, 0, nullptr, 0};
+  e2.sa[0] = sc + 1;
+  e2.sa[1] = sc + 3;
+  rc = launch_gemm_bf16(two, 1, e2, st, "fp8 mode dT = G Y | dY = G^T T");
+  if (rc) return rc;
+  // dW = s_x (x_q^T dT) (split-K slabs) | dX = s_w (dT W_q^T)
+  EpiScaled<EpiStoreMulti> e3{};
+  e3.inner.out[0] = EpiOut{p.dw_slab, dy, dx * dy, nullptr, 0, nullptr, 0};
+  e3.sa[0] = sc + 0;
+  rc = launch_gemm_bf16(one_problem(p.xtb, br, p.dttb, br, dx, dy, br, p.dw_kchunk), p.dw_splits, e3, st,
+                        "fp8 mode dW = X^T dT");
+  if (rc) return rc;
+  EpiScaled<EpiStoreMulti> e4{};
+  e4.inner.out[0] = EpiOut{grad_x, dx, 0, nullptr, 0, nullptr, 0};
+  e4.sa[0] = sc + 2;
+  rc = launch_gemm_bf16(one_problem(p.dtb, dy, p.wb, dy, br, dx, dy), 1, e4, st, "fp8 mode dX = dT W^T");
   if (rc) return rc;
   return launch_slab_reduce_ld(p.dw_slab, p.dw_splits, dx, dy, grad_w, dy, st, "slab_reduce_ld_kernel");
 }
@@ -336,7 +460,9 @@ static int check_common(const char* fn, int64_t br, int64_t b, int64_t row_offse
   MI_CHECK_ARG(row_offset >= 0 && row_offset + br <= b, "%s: row block [%lld, %lld) outside [0, %lld)", fn,
                (long long)row_offset, (long long)(row_offset + br), (long long)b);
   MI_CHECK_ARG(dx >= 1 && dy >= 1, "%s: embedding widths must be >= 1", fn);
-  MI_CHECK_ARG(precision == MI_PREC_F32 || precision == MI_PREC_BF16, "%s: unknown precision %d", fn, precision);
+  MI_CHECK_ARG(precision == MI_PREC_F32 || precision == MI_PREC_BF16 || precision == MI_PREC_BF16X3 ||
+                   precision == MI_PREC_FP8,
+               "%s: unknown precision %d", fn, precision);
   return MI_OK;
 }
 
@@ -367,6 +493,15 @@ int mi_bilinear_fwd(const float* x, const float* y, const float* w, const int64_
     return MI_EWORKSPACE;
   }
   hipStream_t st = (hipStream_t)stream;
+  if (precision == MI_PREC_FP8) {
+    if (!fp8_ok(b_rows, b, d_img, d_txt, precision, w != nullptr)) {
+      set_error("mi_bilinear_fwd: the fp8 mode needs a weight matrix, batch sizes that are multiples of 8 and widths that "
+                "are multiples of 16");
+      return MI_ESHAPE;
+    }
+    return bilinear_fwd_fp8(x, y, w, sid_rows, sid_cols, b_rows, b, row_offset, d_img, d_txt, estimator, loss_out, stats,
+                            partials_out, scores_out, p, st);
+  }
   if (fast_ok(b_rows, b, d_img, d_txt, precision, w != nullptr))
     return bilinear_fwd_fast(x, y, w, sid_rows, sid_cols, b_rows, b, row_offset, d_img, d_txt, estimator, need_grad,
                              loss_out, stats, partials_out, scores_out, p, st);
@@ -394,6 +529,19 @@ int mi_bilinear_bwd(const float* x, const float* y, const float* w, const int64_
     return MI_EWORKSPACE;
   }
   hipStream_t st = (hipStream_t)stream;
+  if (precision == MI_PREC_FP8) {
+    if (!fp8_ok(b_rows, b, d_img, d_txt, precision, w != nullptr)) {
+      set_error("mi_bilinear_bwd: the fp8 mode needs a weight matrix, batch sizes that are multiples of 8 and widths that "
+                "are multiples of 16");
+      return MI_ESHAPE;
+    }
+    if (!workspace_from_forward) {
+      rc = fp8_prep_and_t(x, y, w, b_rows, b, d_img, d_txt, p, st);
+      if (rc) return rc;
+    }
+    return bilinear_bwd_fp8(sid_rows, sid_cols, b_rows, b, row_offset, d_img, d_txt, stats, grad_out, grad_x, grad_y, grad_w,
+                            p, st);
+  }
   if (fast_ok(b_rows, b, d_img, d_txt, precision, w != nullptr)) {
     if (!workspace_from_forward) {  // rebuild the bf16 operand copies, T and the fused sums
       rc = fast_prep_and_t(x, y, w, sid_rows, sid_cols, b_rows, b, d_img, d_txt, p, st);

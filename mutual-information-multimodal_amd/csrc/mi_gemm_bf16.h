@@ -107,6 +107,17 @@ __device__ __forceinline__ void wait_vmcnt_barrier_n() {
   asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
 }
 
+// ---- bf16x3: fp32-grade products from three bf16 MFMAs.  v = hi + lo + O(2^-17 |v|) with hi = bf16(v), lo = bf16(v - hi);
+// a . b ~= hi_a hi_b + hi_a lo_b + lo_a hi_b.  Instead of three GEMMs the K dimension is tripled: the operand on the A
+// side of a product is stored as [hi | hi | lo] along K (role 1), the operand on the B side as [hi | lo | hi] (role 2),
+// and the unchanged bf16 kernels run over K' = 3 K.
+__device__ __forceinline__ void split3_offsets(int role, int64_t K, int64_t& hi0, int64_t& hi1, int64_t& lo) {
+  hi0 = 0;
+  hi1 = role == 1 ? K : 2 * K;
+  lo = role == 1 ? 2 * K : K;
+}
+__device__ __forceinline__ float bf16_residual(float v) { return v - (float)(bf16_t)v; }
+
 struct GemmBf16Problem {
   const bf16_t* a;
   int64_t lda;
@@ -139,6 +150,8 @@ struct EpiOut {
   bf16_t* bf_frag;      // fragment-major copy or null (needs M % 32 == 0, N % 16 == 0): the 8 elements
                         // [row][16 kk + 8 h .. + 7] sit at ((row / 32 * (N / 16) + kk) * 64 + 32 h + row % 32) * 8, i.e. one
                         // 1 KB block per (32-row block, 16-deep step) in the lane order of an MFMA 32x32x16 operand
+  int split_bf, split_bf_t;  // bf16x3 roles of bf ([M][3 N]) and bf_t ([N][3 M]); 0: plain.  ld_bf / ld_bf_t then are
+                             // the NATURAL widths N and M (staged shapes only: M, N multiples of 8)
 };
 
 __device__ __forceinline__ int64_t frag_major_offset(int64_t row, int64_t col8, int64_t n_cols) {
@@ -244,6 +257,56 @@ __device__ __forceinline__ void wave_tile_store_bf16(f32x16 (&acc)[2][2], char* 
   }
 }
 
+// bf16x3 variant of the tile store: the natural widths are N (row-major) and M (transposed); the outputs are [M][3 N] and
+// [N][3 M] with the hi part written twice and the residual once (split3_offsets).  role == 0: plain store.
+__device__ __forceinline__ void wave_tile_store_split(f32x16 (&acc)[2][2], char* lds, bf16_t* rm, int role_rm, bf16_t* tr,
+                                                      int role_tr, int64_t mb, int64_t nb, int64_t M, int64_t N) {
+  int64_t r0 = 0, r1 = 0, rl = 0, t0 = 0, t1 = 0, tl = 0;
+  split3_offsets(role_rm, N, r0, r1, rl);
+  split3_offsets(role_tr, M, t0, t1, tl);
+  const int64_t ld_rm = role_rm ? 3 * N : N, ld_tr = role_tr ? 3 * M : M;
+  wave_tile_store_bf16(acc, lds, rm, ld_rm, tr, ld_tr, mb, nb, M, N);
+  if (!role_rm && !role_tr) return;
+  wave_tile_store_bf16(acc, lds, role_rm ? rm + r1 : nullptr, ld_rm, role_tr ? tr + t1 : nullptr, ld_tr, mb, nb, M, N);
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = bf16_residual(acc[a][b][r]);
+  wave_tile_store_bf16(acc, lds, role_rm ? rm + rl : nullptr, ld_rm, role_tr ? tr + tl : nullptr, ld_tr, mb, nb, M, N);
+}
+
+// Store a wave's 64 x 64 fp32 tile row-major through the wave's LDS staging area, 32 rows at a time, so that every global
+// store is a 16-byte chunk of a 256-byte row segment.  (The direct accumulator-layout stores are 64 four-byte stores per
+// lane; in the in-kernel stamps of the backward's dW | dX launch they were 13.7 k of the 29.4 k cycles of a workgroup.)
+// Needs ld % 4 == 0, N % 4 == 0 and a 16-byte aligned base; elements beyond M x N are dropped.
+__device__ __forceinline__ void wave_tile_store_f32(f32x16 (&acc)[2][2], char* lds, float* dst, int64_t ld, int64_t mb,
+                                                    int64_t nb, int64_t M, int64_t N) {
+  constexpr int P = 272;  // bytes per staged row: 64 floats + 16 of padding (32 rows: 8,704 bytes <= kEpiLdsPerWave)
+  const int lane = threadIdx.x & 63;
+  const int col_l = lane & 31, half = lane >> 5;
+#pragma unroll
+  for (int tm = 0; tm < 2; ++tm) {
+    wave_lds_fence();
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row_l = (r & 3) + 8 * (r >> 2) + 4 * half;
+        *reinterpret_cast<float*>(lds + row_l * P + (tn * 32 + col_l) * 4) = acc[tm][tn][r];
+      }
+    wave_lds_fence();
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int idx = it * 64 + lane, row_l = idx >> 4, c4 = idx & 15;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(lds + row_l * P + c4 * 16);
+      const int64_t grow = mb + tm * 32 + row_l, gcol = nb + c4 * 4;
+      if (grow < M && gcol < N) *reinterpret_cast<f32x4*>(dst + grow * ld + gcol) = v;
+    }
+  }
+}
+
 struct EpiStoreMulti {
   static constexpr bool kReducesPartial = false;
   EpiOut out[2];
@@ -252,8 +315,11 @@ struct EpiStoreMulti {
     const EpiOut& o = out[prob];
     const bool staged = (M % 8 == 0) && (N % 8 == 0) && (!o.bf || o.ld_bf % 8 == 0) && (!o.bf_t || o.ld_bf_t % 8 == 0);
     // (a fragment-major output is only requested for shapes that take the staged path: M % 32 == 0, N % 16 == 0)
-    if (o.f32 || (o.bf && !staged)) {
-      float* f = o.f32 ? o.f32 + (int64_t)zsplit * o.slab_stride : nullptr;
+    float* f32dst = o.f32 ? o.f32 + (int64_t)zsplit * o.slab_stride : nullptr;
+    const bool f32_staged = f32dst && N % 4 == 0 && o.ld_f32 % 4 == 0 && ((uintptr_t)f32dst & 15) == 0;
+    if (f32_staged) wave_tile_store_f32(acc, lds, f32dst, o.ld_f32, mb, nb, M, N);
+    if ((o.f32 && !f32_staged) || (o.bf && !staged)) {
+      float* f = f32_staged ? nullptr : f32dst;
       bf16_t* bfd = staged ? nullptr : o.bf;
       foreach_acc(acc, mb, nb, [&](int64_t row, int64_t col, float v) {
         if (row < M && col < N) {
@@ -262,7 +328,9 @@ struct EpiStoreMulti {
         }
       });
     }
-    if (staged) {
+    if (staged && (o.split_bf || o.split_bf_t)) {
+      wave_tile_store_split(acc, lds, o.bf, o.split_bf, o.bf_t, o.split_bf_t, mb, nb, M, N);  // consumes acc: last use
+    } else if (staged) {
       if (o.bf || o.bf_t || o.bf_frag)
         wave_tile_store_bf16(acc, lds, o.bf, o.ld_bf, o.bf_t, o.ld_bf_t, mb, nb, M, N, o.bf_frag);
     } else if (o.bf_t) {
@@ -387,6 +455,7 @@ struct EpiGradScore2 {
   const float* grad_out;
   bf16_t* g;
   bf16_t* gt;
+  int split;  // bf16x3: g is [M][3 N], gt is [N][3 M], both in the A-side role (staged shapes only)
   __device__ __forceinline__ void operator()(f32x16 (&acc)[2][2], int64_t mb, int64_t nb, int64_t M, int64_t N, int,
                                              int, char* lds) const {
     const float go = grad_out ? grad_out[0] : 1.0f;
@@ -450,7 +519,9 @@ struct EpiGradScore2 {
           }
         }
     }
-    if (staged) {
+    if (staged && split) {
+      wave_tile_store_split(acc, lds, g, 1, gt, 1, mb, nb, M, N);
+    } else if (staged) {
       wave_tile_store_bf16(acc, lds, g, N, gt, M, mb, nb, M, N);
     } else {
       foreach_acc4(acc, mb, nb, [&](int64_t row0, int64_t col, float v0, float v1, float v2, float v3) {
@@ -764,9 +835,11 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_glds4_kernel(GemmBf16Args ar
   constexpr int kk0 = 0;
   constexpr int NST = 4, PCS = 2 * NI;  // stages; LDS-DMA pieces per wave and tile
   const int64_t nt = (kend - kbeg) / kG2KT;
+  MI_STAMP(0);
   for (int t = 0; t < NST - 1; ++t)
     if (t < nt) issue_tile(t, t);
   for (int64_t t = 0; t < nt; ++t) {
+    if (t == 1) MI_STAMP(1);
     const int buf = (int)(t & (NST - 1));
     // tile t landed (own pieces: all but the younger tiles' may stay in flight), then everybody's; every wave has left
     // tile t - 1, whose stage the issue below refills
@@ -799,8 +872,10 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_glds4_kernel(GemmBf16Args ar
       __builtin_amdgcn_sched_barrier(0);
     }
   }
+  MI_STAMP(2);
   __syncthreads();  // all fragment reads done: the stages are free for the epilogue's staging areas
   epi(acc, m0 + wm * 64, n0 + wn * 64, P.m, P.n, prob, zsplit, smem_raw + wave * kEpiLdsPerWave);
+  MI_STAMP(3);
 }
 
 // ------------------------------------------------------------------------------------------------ pipelined kernel
@@ -1328,6 +1403,8 @@ struct CvtJob {
   int n_slab;           // > 1: in holds n_slab partial sums [n_slab][R][C], added in slab order before the conversion
   int64_t slab_stride;  // elements between slabs
   bf16_t* out_frag;     // fragment-major copy (see EpiOut::bf_frag; R % 32 == 0, C % 16 == 0) or null
+  int split_rm;         // bf16x3 mode (split3_offsets): out_rm is [R][3 C] holding hi and lo parts; 0: plain bf16
+  int split_t;          // same for out_t, [C][3 R]
 };
 // equal-id flags of the fused bilinear kernel, computed by spare workgroups of the conversion launch (blockIdx.z == 3)
 struct DupFlagJob {
@@ -1394,7 +1471,17 @@ __device__ __forceinline__ void cvt_tile_block(const CvtJob& J, int bx, int by, 
     for (int e = 0; e < 4; ++e) tile[rl][4 * tx + e] = v[e];
     if ((J.out_rm || J.out_frag) && r < J.R && c < J.C) {
       const bf16x4 o = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
-      if (J.out_rm) *reinterpret_cast<bf16x4*>(J.out_rm + r * J.C + c) = o;
+      if (J.out_rm && !J.split_rm) *reinterpret_cast<bf16x4*>(J.out_rm + r * J.C + c) = o;
+      if (J.out_rm && J.split_rm) {
+        int64_t h0, h1, lo;
+        split3_offsets(J.split_rm, J.C, h0, h1, lo);
+        const bf16x4 l = {(bf16_t)bf16_residual(v[0]), (bf16_t)bf16_residual(v[1]), (bf16_t)bf16_residual(v[2]),
+                          (bf16_t)bf16_residual(v[3])};
+        bf16_t* row = J.out_rm + r * 3 * J.C + c;
+        *reinterpret_cast<bf16x4*>(row + h0) = o;
+        *reinterpret_cast<bf16x4*>(row + h1) = o;
+        *reinterpret_cast<bf16x4*>(row + lo) = l;
+      }
       if (J.out_frag) *reinterpret_cast<bf16x4*>(J.out_frag + frag_major_offset(r, c & ~(int64_t)7, J.C) + (c & 4)) = o;
     }
   }
@@ -1407,7 +1494,18 @@ __device__ __forceinline__ void cvt_tile_block(const CvtJob& J, int bx, int by, 
     if (c < J.C && r < J.R) {
       const bf16x4 o = {(bf16_t)tile[4 * tx][cl], (bf16_t)tile[4 * tx + 1][cl], (bf16_t)tile[4 * tx + 2][cl],
                         (bf16_t)tile[4 * tx + 3][cl]};
-      *reinterpret_cast<bf16x4*>(J.out_t + c * J.R + r) = o;
+      if (!J.split_t) {
+        *reinterpret_cast<bf16x4*>(J.out_t + c * J.R + r) = o;
+      } else {
+        int64_t h0, h1, lo;
+        split3_offsets(J.split_t, J.R, h0, h1, lo);
+        const bf16x4 l = {(bf16_t)bf16_residual(tile[4 * tx][cl]), (bf16_t)bf16_residual(tile[4 * tx + 1][cl]),
+                          (bf16_t)bf16_residual(tile[4 * tx + 2][cl]), (bf16_t)bf16_residual(tile[4 * tx + 3][cl])};
+        bf16_t* row = J.out_t + c * 3 * J.R + r;
+        *reinterpret_cast<bf16x4*>(row + h0) = o;
+        *reinterpret_cast<bf16x4*>(row + h1) = o;
+        *reinterpret_cast<bf16x4*>(row + lo) = l;
+      }
     }
   }
 }
@@ -1481,8 +1579,8 @@ static inline int launch_cvt_transpose3(const CvtJobs& jobs, hipStream_t st, con
 // The bilinear forward used to open with two short launches, the second waiting for the first: the fp32 -> bf16
 // conversions (9 us) and T = X W on 128 tiles (10 us with half the chip idle); a launch of this size costs ~4 us in
 // ramp and drain alone.  Here both are ONE grid: blocks [0, n_t) compute a 128 x 128 tile of T straight from the fp32
-// operands (converted on the way into LDS: X as it lies, W transposed by loading it with the lanes along n, so both LDS
-// images are K-contiguous with the 144-byte pitch of gemm_bf16_kernel), all other blocks do the conversions nobody in
+// operands (converted on the way into LDS, both as they lie: X rows are K-contiguous for ds_read_b128, the [k][n] image
+// of W feeds the B fragments through the transposing ds_read_b64_tr_b16), all other blocks do the conversions nobody in
 // this launch depends on (X^T and W for the backward's products, Y row-major and fragment-major, the equal-id flags) on
 // the CUs the tiles leave free.  T is rounded exactly as before: bf16 operands, fp32 accumulation, one rounding to bf16.
 struct PrepTArgs {
@@ -1491,17 +1589,19 @@ struct PrepTArgs {
   int64_t m, n, k;   // k % 64 == 0, n % 128 == 0
   bf16_t* tb;        // [m][n]
   bf16_t* tfb;       // fragment-major copy (EpiOut::bf_frag) or null
-  int n_t;           // tiles of T
+  int n_t;           // blocks of the T role (tiles, padded to 8 x tiles-per-panel x ceil(panels / 8))
   int job_begin[6];  // conversion blocks (counted from n_t): first block of job q; [4] = flags, [5] = end
   int job_nx[4];     // 64-column tiles per tile row of job q
   CvtJobs jobs;
 };
-constexpr size_t kPrepTSmem = 2 * 2 * kTile * kG2LD * sizeof(bf16_t);  // 73,728 bytes (>= the conversion tile, 16,640)
+constexpr int kPrepTLdB = 160;  // W image row pitch in bf16 elements (128 columns + 32 of padding = 320 bytes)
+constexpr size_t kPrepTSmem = (2 * kTile * kG2LD + 2 * kG2KT * kPrepTLdB) * sizeof(bf16_t);  // 77,824 bytes
 
 static __global__ __launch_bounds__(256, 2) void bilinear_prep_t_kernel(PrepTArgs a) {
   kernarg_prefetch<(int)sizeof(PrepTArgs)>();
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   const int blk = (int)blockIdx.x;
+  MI_STAMP(0);
   if (blk >= a.n_t) {  // ---- conversion roles
     float(*tile)[65] = reinterpret_cast<float(*)[65]>(smem_raw);
     const int c = blk - a.n_t;
@@ -1515,19 +1615,29 @@ static __global__ __launch_bounds__(256, 2) void bilinear_prep_t_kernel(PrepTArg
     while (q < 3 && c >= a.job_begin[q + 1]) ++q;
     const int t = c - a.job_begin[q];
     cvt_tile_block(a.jobs.j[q], t % a.job_nx[q], t / a.job_nx[q], tile);
+    MI_STAMP(5);
     return;
   }
-  // ---- a tile of T
-  bf16_t* As = reinterpret_cast<bf16_t*>(smem_raw);  // [2][128 rows][72]
-  bf16_t* Bs = As + 2 * kTile * kG2LD;               // [2][128 n][72]
-  const int nbx = (int)(a.n / kTile);
-  const int64_t m0 = (int64_t)(blk / nbx) * kTile, n0 = (int64_t)(blk % nbx) * kTile;
+  // ---- a 128 x 128 tile of T.  What bounds this role is bytes through the fabric (the fp32 operands are twice the
+  // bf16 copies the plain GEMM reads, every X panel is wanted by n / 128 tiles): the tiles of one row panel run back to
+  // back on ONE XCD (xcd_decode), so its L2 fetches the panel once and keeps W.  (A 128 x 64 tiling with a 128-deep
+  // k-step -- twice the tiles, half the round trips -- moved 96 MB instead of 64 and took 22.9 us instead of 16.4.)
+  bf16_t* As = reinterpret_cast<bf16_t*>(smem_raw);  // [2][128 rows][72]: X as it lies, K-contiguous
+  bf16_t* Bs = As + 2 * kTile * kG2LD;               // [2][64 k][160]: W as it lies, n-contiguous; the B fragments come
+                                                     // out K-major through ds_read_b64_tr_b16 (320-byte rows: the four
+                                                     // rows of a transposed read fall on disjoint quarters of the banks)
+  int nb_, mb_;
+  if (!xcd_decode((int)(a.n / kTile), (int)((a.m + kTile - 1) / kTile), nb_, mb_)) return;
+  const int64_t m0 = (int64_t)mb_ * kTile, n0 = (int64_t)nb_ * kTile;
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63;
   const int wm = wave >> 1, wn = wave & 1;
   const int r32 = lane & 31, half = lane >> 5;
-  const int xr = tid >> 4, xc = tid & 15;   // X staging: rows xr + 16 q, float4 number xc of the 64-wide k slice
-  const int wnl = tid & 127, wk = tid >> 7;  // W staging: column wnl, k rows 32 wk .. 32 wk + 31 of the slice
+  const int xr = tid >> 4, xc = tid & 15;  // X staging: rows xr + 16 q, float4 number xc of the 64-wide k slice
+  const int wk = tid >> 5, wc = tid & 31;  // W staging: k rows wk + 8 q of the slice, float4 number wc of the 128 columns
+  // transposed read (guide T10): lane 4 q + p of a 16-lane group addresses row q, columns 4 p .. 4 p + 3 of a 4 x 16 block
+  // and receives column (lane & 15) of its four rows; a lane's B fragment is rows 8 (lane >> 5) .. + 7 of column lane & 31
+  const int tr_off = (8 * half + ((lane >> 2) & 3)) * (kPrepTLdB * 2) + (wn * 64 + 16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
 
   f32x16 acc[2][2];
 #pragma unroll
@@ -1537,8 +1647,7 @@ static __global__ __launch_bounds__(256, 2) void bilinear_prep_t_kernel(PrepTArg
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-  f32x4 rx[8];
-  float rw[32];
+  f32x4 rx[8], rw[8];
   const float* xp[8];
 #pragma unroll
   for (int q = 0; q < 8; ++q) {
@@ -1546,12 +1655,12 @@ static __global__ __launch_bounds__(256, 2) void bilinear_prep_t_kernel(PrepTArg
     if (row >= a.m) row = a.m - 1;  // clamped rows only feed outputs the epilogue drops
     xp[q] = a.x + row * a.k + 4 * xc;
   }
-  const float* wp = a.w + (int64_t)(32 * wk) * a.n + n0 + wnl;
+  const float* wp = a.w + (int64_t)wk * a.n + n0 + 4 * wc;
   auto load_tile = [&](int64_t k0) {
 #pragma unroll
     for (int q = 0; q < 8; ++q) rx[q] = *reinterpret_cast<const f32x4*>(xp[q] + k0);
 #pragma unroll
-    for (int j = 0; j < 32; ++j) rw[j] = wp[(k0 + j) * a.n];
+    for (int q = 0; q < 8; ++q) rw[q] = *reinterpret_cast<const f32x4*>(wp + (k0 + 8 * q) * a.n);
   };
   auto store_tile = [&](int buf) {
 #pragma unroll
@@ -1560,11 +1669,9 @@ static __global__ __launch_bounds__(256, 2) void bilinear_prep_t_kernel(PrepTArg
       *reinterpret_cast<bf16x4*>(&As[(buf * kTile + xr + 16 * q) * kG2LD + 4 * xc]) = o;
     }
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      bf16x8 o;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) o[j] = (bf16_t)rw[8 * e + j];
-      *reinterpret_cast<bf16x8*>(&Bs[(buf * kTile + wnl) * kG2LD + 32 * wk + 8 * e]) = o;
+    for (int q = 0; q < 8; ++q) {
+      const bf16x4 o = {(bf16_t)rw[q][0], (bf16_t)rw[q][1], (bf16_t)rw[q][2], (bf16_t)rw[q][3]};
+      *reinterpret_cast<bf16x4*>(&Bs[(buf * kG2KT + wk + 8 * q) * kPrepTLdB + 4 * wc]) = o;
     }
   };
 
@@ -1572,12 +1679,13 @@ static __global__ __launch_bounds__(256, 2) void bilinear_prep_t_kernel(PrepTArg
   load_tile(0);
   store_tile(0);
   __syncthreads();
+  MI_STAMP(1);
   for (int t = 0; t < nt; ++t) {
     const int buf = t & 1;
     const bool more = t + 1 < nt;
     if (more) load_tile((int64_t)(t + 1) * kG2KT);
     const bf16_t* at = As + buf * kTile * kG2LD;
-    const bf16_t* bt = Bs + buf * kTile * kG2LD;
+    const char* bt = reinterpret_cast<const char*>(Bs + buf * kG2KT * kPrepTLdB) + tr_off;
 #pragma unroll
     for (int kk = 0; kk < kG2KT / 16; ++kk) {
       bf16x8 af[2], bfr[2];
@@ -1585,19 +1693,28 @@ static __global__ __launch_bounds__(256, 2) void bilinear_prep_t_kernel(PrepTArg
       for (int tm = 0; tm < 2; ++tm)
         af[tm] = *reinterpret_cast<const bf16x8*>(&at[(wm * 64 + tm * 32 + r32) * kG2LD + kk * 16 + 8 * half]);
 #pragma unroll
-      for (int tn = 0; tn < 2; ++tn)
-        bfr[tn] = *reinterpret_cast<const bf16x8*>(&bt[(wn * 64 + tn * 32 + r32) * kG2LD + kk * 16 + 8 * half]);
+      for (int tn = 0; tn < 2; ++tn) {
+        using lds_b4 = __attribute__((address_space(3))) bf16x4;
+        const char* pb = bt + kk * 16 * (kPrepTLdB * 2) + tn * 64;
+        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4*)(pb));
+        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4*)(pb + 4 * (kPrepTLdB * 2)));
+        bfr[tn] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      }
 #pragma unroll
       for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
         for (int tn = 0; tn < 2; ++tn)
           acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[tm], bfr[tn], acc[tm][tn], 0, 0, 0);
     }
+    if (t == 0) MI_STAMP(2);
     if (more) store_tile(buf ^ 1);
     __syncthreads();
+    if (t == 0) MI_STAMP(3);
   }
+  MI_STAMP(4);
   wave_tile_store_bf16(acc, smem_raw + wave * kEpiLdsPerWave, a.tb, a.n, nullptr, 0, m0 + wm * 64, n0 + wn * 64, a.m, a.n,
                        a.tfb);
+  MI_STAMP(5);
 }
 
 // conversions: up to four CvtJob (64 x 64 tiles each) + the flag job; returns MI_EINVAL for shapes the fused kernel does
@@ -1610,7 +1727,7 @@ static inline int launch_prep_t(const float* x, const float* w, int64_t m, int64
     return MI_EINVAL;
   PrepTArgs a{};
   a.x = x; a.w = w; a.m = m; a.n = n; a.k = k; a.tb = tb; a.tfb = tfb;
-  a.n_t = (int)(((m + kTile - 1) / kTile) * (n / kTile));
+  a.n_t = (int)(8 * (n / kTile) * (((m + kTile - 1) / kTile + 7) / 8));  // padded for the XCD mapping
   a.jobs = jobs;
   int total = 0;
   for (int q = 0; q < 4; ++q) {
@@ -1626,6 +1743,9 @@ static inline int launch_prep_t(const float* x, const float* w, int64_t m, int64
   if (jobs.dup.na > 0) total += jobs.dup.na * ((jobs.dup.nb + 63) / 64);
   a.job_begin[5] = total;
   MI_SET_DYN_SMEM(bilinear_prep_t_kernel, kPrepTSmem, "hipFuncSetAttribute(bilinear_prep_t_kernel)");
+#ifdef MI_STAMPS
+  stamp_select(what, st);
+#endif
   {
     ProfScope prof_(what, st);
     hipLaunchKernelGGL(bilinear_prep_t_kernel, dim3((unsigned)(a.n_t + total)), dim3(256), kPrepTSmem, st, a);

@@ -310,8 +310,12 @@ def fused_mi_bound(embedding_img: torch.Tensor, embedding_txt: torch.Tensor, stu
     ``precision`` defaults to "f32" (exact fp32 products on the fp32-input MFMA): the reference critic is fp32
     throughout and this is the mode whose gradients match it.  "bf16" (bf16 MFMA operands, fp32
     accumulate) is the fast mode; it moves the gradients of this heavily cancelling loss by up to a few percent of
-    max|grad| against the fp32 reference and must be asked for explicitly.  Embeddings in float64 are cast to float32
-    (the reference would run them in fp64; this path computes in fp32).
+    max|grad| against the fp32 reference and must be asked for explicitly.  "bf16x3" (BilinearCritic only) splits every
+    operand into two bf16 parts and spends three bf16 MFMAs per product: fp32-grade gradients at several times the speed
+    of "f32".  "fp8" (BilinearCritic only) quantises the embeddings, the weight and T = x W to e4m3 with per-tensor scales
+    and runs both forward products on the fp8 MFMA (BASELINE configs[4]); its results match an oracle fed the same
+    quantised values, not the fp32 reference.  Embeddings in float64 are cast to float32 (the reference would run them in fp64; this path computes in
+    fp32).
     """
     from . import model as _model  # local import: model.py imports nothing from here
 
@@ -328,6 +332,8 @@ def fused_mi_bound(embedding_img: torch.Tensor, embedding_txt: torch.Tensor, stu
     sid = study_id_codes(study_id, embedding_img.device)
     if sid.numel() != embedding_img.shape[0]:
         raise ValueError("study_id length must equal the batch size")
+    if prec in (_hip.MI_PREC_BF16X3, _hip.MI_PREC_FP8) and not isinstance(critic, _model.BilinearCritic):
+        raise ValueError(f'precision="{precision}" is implemented for BilinearCritic only')
     if isinstance(critic, _model.BilinearCritic):
         loss, stats, scores = BilinearCriticFn.apply(embedding_img, embedding_txt, critic.weight, sid, code, prec,
                                                      bool(return_scores))

@@ -22,7 +22,7 @@ def construct_training_parameters(argv=None):
     p.add_argument('--embed_dim_img', default=128, type=int)
     p.add_argument('--embed_dim_txt', default=128, type=int)
     p.add_argument('--steps_per_epoch', default=20, type=int)
-    p.add_argument('--precision', default='f32', choices=['bf16', 'f32'])  # the reference is fp32; bf16 is the fast mode
+    p.add_argument('--precision', default='f32', choices=['bf16', 'f32', 'bf16x3'])  # the reference is fp32; bf16 is the fast mode
     p.add_argument('--synthetic_encoders', action='store_true')
     p.add_argument('--img_size', default=256, type=int)                        # helpers.py:130
     p.add_argument('--output_channels', default=1, type=int)                   # helpers.py:131

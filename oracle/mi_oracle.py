@@ -246,6 +246,62 @@ def bilinear_step_rounded(x, y, w, study_id: Sequence, estimator: str, row_block
     return {"scores": s, "loss": loss, "dx": dt @ wb.t(), "dy": dy, "dw": xb[rows].t() @ dt, "dt": dt}
 
 
+# ----------------------------------------------------------------------------------------------------
+# fp8 critic (BASELINE configs[4]; SURVEY.md hazard H7: parity is defined on identically quantised inputs)
+# ----------------------------------------------------------------------------------------------------
+E4M3_MAX = 448.0
+
+
+def quant_e4m3(v: torch.Tensor) -> torch.Tensor:
+    """Round to the OCP e4m3fn grid (what gfx950's v_cvt_pk_fp8_f32 produces for |v| <= 448): 3 mantissa bits, normal
+    exponents -6 .. 8, subnormal step 2^-9, round-to-nearest-even, saturating at +-448.  Returns the VALUES in v's dtype
+    (every e4m3 value is exact in bf16, fp32 and fp64)."""
+    a = v.abs().double()
+    e = torch.floor(torch.log2(torch.clamp(a, min=2.0 ** -20)))
+    e = torch.clamp(e, min=-6.0, max=8.0)
+    step = torch.pow(torch.tensor(2.0, dtype=torch.float64), e - 3.0)
+    q = torch.round(a / step) * step          # torch.round is round-half-to-even; a / step is exact (power of two)
+    q = torch.clamp(q, max=E4M3_MAX)
+    return (torch.sign(v).double() * q).to(v.dtype)
+
+
+def fp8_scale(t: torch.Tensor) -> torch.Tensor:
+    """Per-tensor scale absmax / 448 in fp32 arithmetic, as the library computes it."""
+    return (t.float().abs().max() / torch.tensor(E4M3_MAX, dtype=torch.float32)).float()
+
+
+def bilinear_step_fp8(x, y, w, study_id: Sequence, estimator: str, row_block: Optional[Tuple[int, int]] = None):
+    """Extension (no reference code).  fp64 forward + backward of S = (x W) y^T under the reference bound with the
+    quantisation and rounding points of the library's fp8 mode (csrc/mi_bilinear.hip, MI_PREC_FP8):
+
+      x, y, w -> e4m3 with per-tensor scales absmax / 448 (scales and the divisions in fp32);
+      T = x_q w_q exactly (fp8 MFMA products are exact, fp32 accumulation) -> e4m3 with its own per-tensor scale;
+      S = T_q y_q^T; bound and masking as the reference;
+      backward on the dequantised operands (straight-through for the quantisers): G = dL/dS rounded to bf16,
+      dT = G y_q rounded to bf16 before dW = x_q^T dT and dX = dT w_q^T;  dY = G^T T_q.
+
+    ``row_block = (offset, rows)`` restricts the image rows (a rank's share of a sharded batch): statistics stay global,
+    dx / dw / dy are the block's terms."""
+    f32 = torch.float32
+    sx, sy, sw = fp8_scale(x), fp8_scale(y), fp8_scale(w)
+    qx = quant_e4m3((x.to(f32) / sx)).double()
+    qy = quant_e4m3((y.to(f32) / sy)).double()
+    qw = quant_e4m3((w.to(f32) / sw)).double()
+    sx, sy, sw = sx.double(), sy.double(), sw.double()
+    t = (sx * sw) * (qx @ qw)
+    st = fp8_scale(t)
+    qt = quant_e4m3((t.to(f32) / st)).double()
+    st = st.double()
+    s = (st * sy) * (qt @ qy.t())
+    loss = bound_from_matrix(s, study_id, estimator)
+    g = matrix_grad_scores(s, study_id)
+    off, rows = row_block if row_block is not None else (0, x.shape[0])
+    gb = round_bf16(g[off:off + rows])
+    dt = round_bf16(sy * (gb @ qy))
+    return {"scores": s, "loss": loss, "dx": sw * (dt @ qw.t()), "dy": st * (gb.t() @ qt[off:off + rows]),
+            "dw": sx * (qx[off:off + rows].t() @ dt), "scales": (float(sx), float(sy), float(sw), float(st))}
+
+
 def separable_step_rounded(x, y, wg, wh, study_id: Sequence, estimator: str):
     """Extension (no reference code).  fp64 forward + backward of S = (x Wg)(y Wh)^T under the reference bound with the
     rounding points of the 16-bit path (mi_bilinear.hip, separable form): x, y, Wg, Wh and the projections A = x Wg,

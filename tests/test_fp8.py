@@ -1,0 +1,95 @@
+"""fp8 mode of the bilinear critic (BASELINE configs[4]; csrc/mi_fp8.h) against the oracle fed identically quantised
+inputs (SURVEY.md hazard H7: orc.bilinear_step_fp8), through the public Python entry point and the C ABI.
+
+Stated tolerances: loss 2e-3 * max(1, |S|max); every gradient 2e-2 * max|grad| (the oracle models the e4m3 quantisers and
+the bf16 roundings of G and dT; what is left is fp32 accumulation order, the native exponential, and the rare element of
+T that sits on an e4m3 rounding boundary and comes out one step apart under the fp32- and the fp64-computed scale).
+GPU tests need an MI355X: python -m pytest tests -m gpu"""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import mi_oracle as orc
+
+
+def test_e4m3_quantiser_matches_torch_cast():
+    """The oracle's explicit e4m3 rounding against torch's float8_e4m3fn cast (OCP e4m3fn, the format of gfx950)."""
+    gen = torch.Generator().manual_seed(0)
+    v = torch.cat([torch.randn(200000, generator=gen) * 120.0, torch.randn(50000, generator=gen) * 0.01,
+                   torch.tensor([0.0, 448.0, -448.0, 447.9, 2.0 ** -9, 2.0 ** -10, 1.5 * 2.0 ** -9, 2.5 * 2.0 ** -9, 0.0156])])
+    v = v.clamp(-448.0, 448.0)
+    assert torch.equal(orc.quant_e4m3(v), v.to(torch.float8_e4m3fn).float())
+    x = torch.randn(48, 64, generator=gen)
+    s = orc.fp8_scale(x)
+    assert float(s) == float(x.abs().max()) / 448.0 or abs(float(s) - float(x.abs().max()) / 448.0) < 1e-9
+    assert float(orc.quant_e4m3(x / s).abs().max()) == 448.0
+
+
+@pytest.fixture(scope="module")
+def dev():
+    from mutual_info_img_txt import _hip
+    _hip.load()
+    return torch.device("cuda:0")
+
+
+def _dup_ids(b):
+    sid = list(range(b))
+    for n in range(max(b // 8, 2)):
+        sid[n] = n - (n % 2)
+    return sid
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("b,dx,dy,est,dup", [(64, 128, 128, "dv", False), (256, 256, 256, "infonce", True),
+                                            (200, 80, 48, "dv", True), (1024, 1024, 1024, "infonce", True)])
+def test_fp8_bilinear_vs_quantised_oracle(dev, b, dx, dy, est, dup):
+    from mutual_info_img_txt import _hip, mi_critics
+    from mutual_info_img_txt.model import BilinearCritic
+    gen = torch.Generator().manual_seed(7 * b + dx)
+    x = torch.randn(b, dx, generator=gen)
+    y = torch.randn(b, dy, generator=gen)
+    w = torch.randn(dx, dy, generator=gen) * (0.3 / math.sqrt(dx))
+    sid = _dup_ids(b) if dup else list(range(b))
+    critic = BilinearCritic(dx, dy)
+    with torch.no_grad():
+        critic.weight.copy_(w)
+    critic.to(dev)
+    xl, yl = x.to(dev).requires_grad_(True), y.to(dev).requires_grad_(True)
+    loss, scores = mi_critics.fused_mi_bound(xl, yl, sid, critic, est, precision="fp8", return_scores=True)
+    loss.sum().backward()
+    torch.cuda.synchronize()
+    o = orc.bilinear_step_fp8(x, y, w, sid, est)
+    sc = max(float(o["scores"].abs().max()), 1.0)
+    serr = float((scores.cpu().double() - o["scores"]).abs().max())
+    errs = {n: float((g.cpu().double() - r).abs().max()) / float(r.abs().max())
+            for n, g, r in (("dx", xl.grad, o["dx"]), ("dy", yl.grad, o["dy"]), ("dw", critic.weight.grad, o["dw"]))}
+    print(f"fp8 B={b}: loss {float(loss.sum()):.6f} vs {float(o['loss'].sum()):.6f}, score err {serr:.2e} (|S|max {sc:.2f}),",
+          {k: f"{v:.1e}" for k, v in errs.items()})
+    assert tuple(loss.shape) == ((1,) if est == "dv" else ())
+    assert abs(float(loss.sum()) - float(o["loss"].sum())) < 2e-3 * sc
+    # a T element one e4m3 step apart moves a score row by ~ |t| |y| / 8: scores are checked in the mean, not the maximum
+    assert float((scores.cpu().double() - o["scores"]).abs().mean()) < 1e-4 * sc
+    for name, err in errs.items():
+        assert err < 2e-2, (name, err)
+
+
+@pytest.mark.gpu
+def test_fp8_rejected_where_not_implemented(dev):
+    from mutual_info_img_txt import _hip, mi_critics
+    from mutual_info_img_txt.model import make_mlp
+    x = torch.randn(32, 16, device=dev)
+    with pytest.raises(ValueError):
+        mi_critics.fused_mi_bound(x, x, list(range(32)), make_mlp(32, [64, 256]).to(dev), "dv", precision="fp8")
+    lib = _hip.load()
+    # widths that are not multiples of 16: MI_ESHAPE through the C ABI, reported as an exception by the binding
+    xs = torch.randn(32, 24, device=dev)
+    w = torch.randn(24, 24, device=dev)
+    sid = torch.arange(32, device=dev)
+    ws = _hip.workspace(lib.mi_bilinear_workspace_bytes(32, 32, 24, 24, _hip.MI_PREC_FP8), dev)
+    loss, stats, rec = torch.zeros(1, device=dev), _hip.new_stats(dev), torch.zeros(_hip.RECORD_FLOATS, device=dev)
+    with pytest.raises((ValueError, _hip.MiCriticError)):
+        _hip.call("mi_bilinear_fwd", dev, xs.data_ptr(), xs.data_ptr(), w.data_ptr(), sid.data_ptr(), sid.data_ptr(), 32, 32, 0,
+                  24, 24, 0, _hip.MI_PREC_FP8, 1, loss.data_ptr(), stats.data_ptr(), rec.data_ptr(), None, ws.data_ptr(),
+                  ws.numel())

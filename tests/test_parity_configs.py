@@ -105,9 +105,11 @@ def test_config1_separable_bf16(dev, dup):
 
 
 # ------------------------------------------------------------------------------------------------ fp32 parity at size
+@pytest.mark.parametrize("precision", ["f32", "bf16x3"])
 @pytest.mark.parametrize("b,d", [(1024, 512), (4096, 512)])
-def test_bilinear_f32_full_size_vs_fp64_oracle(dev, b, d):
-    """The parity mode at BASELINE configs 3 / 4 sizes (it was only exercised at B <= 200 before)."""
+def test_bilinear_f32_full_size_vs_fp64_oracle(dev, b, d, precision):
+    """The parity modes at BASELINE configs 3 / 4 sizes against the UNROUNDED fp64 oracle, at DESIGN.md section 2's fp32
+    tolerances: "f32" (exact fp32 products) and "bf16x3" (two-part bf16 operands, three MFMAs per product)."""
     from mutual_info_img_txt import mi_critics
     from mutual_info_img_txt.model import BilinearCritic
     gen = torch.Generator().manual_seed(b)
@@ -120,11 +122,70 @@ def test_bilinear_f32_full_size_vs_fp64_oracle(dev, b, d):
         critic.weight.copy_(w)
     critic.to(dev)
     xl, yl = x.to(dev).requires_grad_(True), y.to(dev).requires_grad_(True)
-    loss = mi_critics.fused_mi_bound(xl, yl, sid, critic, "dv", precision="f32")
+    loss = mi_critics.fused_mi_bound(xl, yl, sid, critic, "dv", precision=precision)
     loss.sum().backward()
     o = orc.matrix_step(lambda a, c, ww: orc.bilinear_scores(a, c, ww), [x.double(), y.double(), w.double()], sid, "dv")
+    print(precision, b, "loss err", abs(float(loss) - float(o["loss"])),
+          {n: f"{float((g.cpu().double() - r).abs().max()) / float(r.abs().max()):.1e}"
+           for n, g, r in zip(("dx", "dy", "dw"), (xl.grad, yl.grad, critic.weight.grad), o["grads"])})
     np.testing.assert_allclose(loss.detach().cpu().numpy(), o["loss"].numpy(), rtol=1e-5, atol=3e-5)
     for name, got, ref in zip(("dx", "dy", "dw"), (xl.grad, yl.grad, critic.weight.grad), o["grads"]):
+        np.testing.assert_allclose(got.cpu().numpy(), ref.numpy(), rtol=2e-3, atol=3e-4 * float(ref.abs().max()), err_msg=name)
+
+
+@pytest.mark.parametrize("b,br,off,dx,dy,est", [(200, 200, 0, 72, 40, "dv"), (512, 128, 256, 256, 128, "infonce")])
+def test_bilinear_bf16x3_small_and_row_block(dev, b, br, off, dx, dy, est):
+    """bf16x3 through the C ABI on shapes the fused fast kernels do not take, and on a row block of a sharded batch
+    (b_rows < b, row_offset > 0: the local dX / dW / partial dY of mutual_info_img_txt/distributed.py)."""
+    from mutual_info_img_txt import _hip
+    lib = _hip.load()
+    gen = torch.Generator().manual_seed(b + dx)
+    x = torch.randn(b, dx, generator=gen)
+    y = torch.randn(b, dy, generator=gen)
+    w = torch.randn(dx, dy, generator=gen) * (0.3 / math.sqrt(dx))
+    sid = _dup_ids(b)
+    xr = x[off:off + br].contiguous().to(dev)
+    yd, wd = y.to(dev), w.to(dev)
+    sidd = torch.as_tensor(orc.sid_to_int(sid)).to(dev)
+    sid_rows = sidd[off:off + br].contiguous()
+    prec = _hip.MI_PREC_BF16X3
+    ws = _hip.workspace(lib.mi_bilinear_workspace_bytes(br, b, dx, dy, prec), dev)
+    loss = torch.zeros(1, device=dev)
+    stats = _hip.new_stats(dev)
+    rec = torch.zeros(_hip.RECORD_FLOATS, device=dev)
+    code = _hip.ESTIMATORS[est]
+    _hip.call("mi_bilinear_fwd", dev, xr.data_ptr(), yd.data_ptr(), wd.data_ptr(), sid_rows.data_ptr(), sidd.data_ptr(), br, b,
+              off, dx, dy, code, prec, 1, loss.data_ptr(), stats.data_ptr(), rec.data_ptr(), None, ws.data_ptr(), ws.numel())
+    o = orc.matrix_step(lambda a, c, ww: orc.bilinear_scores(a, c, ww), [x.double(), y.double(), w.double()], sid, est)
+    if br == b:
+        assert abs(float(loss) - float(o["loss"])) < 3e-5
+        go = torch.ones(1, device=dev)
+        gx, gy, gw = torch.zeros_like(xr), torch.zeros_like(yd), torch.zeros_like(wd)
+        _hip.call("mi_bilinear_bwd", dev, xr.data_ptr(), yd.data_ptr(), wd.data_ptr(), sid_rows.data_ptr(), sidd.data_ptr(),
+                  br, b, off, dx, dy, prec, stats.data_ptr(), go.data_ptr(), gx.data_ptr(), gy.data_ptr(), gw.data_ptr(),
+                  ws.data_ptr(), ws.numel(), 1)
+        for name, got, ref in zip(("dx", "dy", "dw"), (gx, gy, gw), o["grads"]):
+            np.testing.assert_allclose(got.cpu().numpy(), ref.numpy(), rtol=2e-3, atol=3e-4 * float(ref.abs().max()),
+                                       err_msg=name)
+        return
+    # row block: the backward needs the GLOBAL statistics (the exchange of distributed.py); take them from a full-batch
+    # forward of the same mode, then compare the block's dX and its partial dY / dW with the oracle's row-block terms
+    xf = x.to(dev)
+    wsf = _hip.workspace(lib.mi_bilinear_workspace_bytes(b, b, dx, dy, prec), dev)
+    statsf = _hip.new_stats(dev)
+    _hip.call("mi_bilinear_fwd", dev, xf.data_ptr(), yd.data_ptr(), wd.data_ptr(), sidd.data_ptr(), sidd.data_ptr(), b, b, 0,
+              dx, dy, code, prec, 0, loss.data_ptr(), statsf.data_ptr(), rec.data_ptr(), None, wsf.data_ptr(), wsf.numel())
+    go = torch.ones(1, device=dev)
+    gx, gy, gw = torch.zeros_like(xr), torch.zeros_like(yd), torch.zeros_like(wd)
+    _hip.call("mi_bilinear_bwd", dev, xr.data_ptr(), yd.data_ptr(), wd.data_ptr(), sid_rows.data_ptr(), sidd.data_ptr(), br, b,
+              off, dx, dy, prec, statsf.data_ptr(), go.data_ptr(), gx.data_ptr(), gy.data_ptr(), gw.data_ptr(), ws.data_ptr(),
+              ws.numel(), 1)
+    g = orc.matrix_grad_scores(o["scores"], sid)[off:off + br]          # [br, b] rows of dL/dS
+    t = x.double()[off:off + br] @ w.double()
+    dt = g @ y.double()
+    refs = {"dx": dt @ w.double().t(), "dy": g.t() @ t, "dw": x.double()[off:off + br].t() @ dt}
+    for name, got in (("dx", gx), ("dy", gy), ("dw", gw)):
+        ref = refs[name]
         np.testing.assert_allclose(got.cpu().numpy(), ref.numpy(), rtol=2e-3, atol=3e-4 * float(ref.abs().max()), err_msg=name)
 
 
