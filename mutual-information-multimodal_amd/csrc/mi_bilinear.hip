@@ -319,7 +319,7 @@ static int fp8_prep_and_t(const float* x, const float* y, const float* w, int64_
   aj.sc = p.f8sc;
   {
     ProfScope prof_("fp8 absmax X Y W", st);
-    hipLaunchKernelGGL(fp8_absmax_kernel, dim3(128, 3), dim3(256), 0, st, aj);
+    hipLaunchKernelGGL(fp8_absmax_kernel, dim3(kAbsmaxBlocks, 3), dim3(256), 0, st, aj);
   }
   MI_LAUNCH_CHECK("fp8_absmax_kernel");
   QuantJobs qj{};

@@ -99,7 +99,7 @@ struct FlashCfg {
 };
 
 // swizzle of image (b), guide T10: XOR on the low four bits of the 16-byte chunk index
-__device__ __forceinline__ int fl_swz(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
+__host__ __device__ constexpr int fl_swz(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
 
 // wave-wide maximum as a wave-uniform value (DPP butterfly inside rows of 16, row broadcasts, lane 63)
 __device__ __forceinline__ float wave_max_uniform(float v) {
@@ -131,6 +131,23 @@ __device__ __forceinline__ void fl_dma16(unsigned voff, const void* sbase, unsig
                : "=&s"(keep)
                : "v"(voff), "s"(sbase), "s"(lds_addr)
                : "memory");
+}
+
+// the same piece inside the pipelined loop, where every instruction costs an issue slot next to the MFMAs (in-kernel
+// stamps: 475 cycles per tile for 8 pieces of 12 instructions each).  The tile's scalar bases are made once per
+// iteration; a piece is then M0 = lds_base + LOFF, one wait state, the load with an immediate offset: 3 instructions.
+// The instruction's immediate offset GOFF is added to the global address AND to the LDS address (M0 + GOFF + 16 lane):
+// LOFF carries only the part of the piece's LDS offset that the immediate does not.
+// M0 is NOT saved: hipcc emits no M0 use of its own in this kernel, which tools/diag/audit_flash_isa.py verifies.
+// The lane offset of piece i is vlane_w ^ XORC (a compile-time constant per piece: the swizzle term is XOR-linear in the
+// piece number), formed in the statement: eight precomputed offsets cost eight registers this kernel does not have.
+template <int LOFF, int GOFF, int XORC>
+__device__ __forceinline__ void fl_dma16_at(unsigned vlane_w, const void* sbase, unsigned lds_base) {
+  unsigned voff;
+  asm volatile("v_xor_b32 %0, %5, %1\n\ts_add_u32 m0, %3, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %2 offset:%6"
+               : "=&v"(voff)
+               : "v"(vlane_w), "s"(sbase), "s"(lds_base), "n"(LOFF), "n"(XORC), "n"(GOFF)
+               : "memory", "scc");
 }
 
 // max of three without the canonicalising v_max(x, x) hipcc puts in front of fmaxf on MFMA outputs (NaNs propagate to
@@ -238,33 +255,42 @@ __device__ __forceinline__ void fl_ring_read_v(bf16x8& f, int addr_lo, int addr_
 // fl_copy_scores (asm: nothing to coalesce, and it sits behind the whole output product), and
 // tools/diag/audit_flash_isa.py checks the compiled kernel for any compiler-issued instruction that touches the
 // destination of an MFMA still in flight.
+// WAIT >= 0: `s_waitcnt lgkmcnt(WAIT)` first (its own volatile statement: volatile asms keep their order); WAIT < 0: none.
+// Only every second MFMA waits, for its own fragment and the next one's: a wait is an issue slot next to the MFMAs
+// whether or not it has anything to wait for (71 of them per streamed tile before).
+template <int WAIT>
+__device__ __forceinline__ void fl_wait_lgkm() {
+  if constexpr (WAIT >= 0) asm volatile("s_waitcnt lgkmcnt(%c0)" ::"i"(WAIT) : "memory");
+}
 template <bool B_IN_ACC, bool FIRST, int WAIT>
 __device__ __forceinline__ void fl_mfma_s(f32x16& acc, const bf16x8& a, const bf16x8& b) {
+  fl_wait_lgkm<WAIT>();
   if constexpr (FIRST) {
     if constexpr (B_IN_ACC)
-      asm volatile("s_waitcnt lgkmcnt(%c3)\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=v"(acc) : "v"(a), "a"(b), "i"(WAIT));
+      asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=v"(acc) : "v"(a), "a"(b));
     else
-      asm volatile("s_waitcnt lgkmcnt(%c3)\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=v"(acc) : "v"(a), "v"(b), "i"(WAIT));
+      asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=v"(acc) : "v"(a), "v"(b));
   } else {
     if constexpr (B_IN_ACC)
-      asm volatile("s_waitcnt lgkmcnt(%c3)\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "a"(b), "i"(WAIT));
+      asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "a"(b));
     else
-      asm volatile("s_waitcnt lgkmcnt(%c3)\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b), "i"(WAIT));
+      asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
   }
 }
 // o += P x V with P (A operand) in VGPRs, V = ring fragment
 template <bool ACC_IN_ACC, bool NOP, int WAIT>
 __device__ __forceinline__ void fl_mfma_o(f32x16& acc, const bf16x8& a, const bf16x8& b) {
+  fl_wait_lgkm<WAIT>();
   if constexpr (NOP) {
     if constexpr (ACC_IN_ACC)
-      asm volatile("s_waitcnt lgkmcnt(%c3)\n\ts_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b), "i"(WAIT));
+      asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
     else
-      asm volatile("s_waitcnt lgkmcnt(%c3)\n\ts_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b), "i"(WAIT));
+      asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
   } else {
     if constexpr (ACC_IN_ACC)
-      asm volatile("s_waitcnt lgkmcnt(%c3)\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b), "i"(WAIT));
+      asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
     else
-      asm volatile("s_waitcnt lgkmcnt(%c3)\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b), "i"(WAIT));
+      asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
   }
 }
 // 20 wait states: covers the 8-pass and the 16-pass rule for "matrix result -> any other reader".
@@ -316,10 +342,13 @@ __device__ __forceinline__ void fl_pin_o(f32x16& v) {
 // Fragment stream of one loop iteration: F[0 .. NK) = row fragments of the NEXT tile (score product, one ds_read_b128
 // each), F[NK .. NK + 2 NT) = transposed fragments of the CURRENT tile (output product, two ds_read_b64_tr_b16 each).
 // lgkmcnt to wait for before the MFMA that consumes F[n] when reads up to F[min(n + AHEAD - 1, last)] have been issued.
+// Waits come in pairs: the MFMA of an even n waits for F[n] AND F[n + 1] (only the reads behind F[n + 1] may be
+// outstanding), the MFMA of an odd n does not wait at all (-1).
 template <int NS, int NV>
 constexpr int fl_wait_count(int n) {
+  if (n & 1) return -1;
   int c = 0;
-  for (int m = n + 1; m <= n + kFlAhead - 1 && m < NS + NV; ++m) c += m < NS ? 1 : 2;
+  for (int m = n + 2; m <= n + kFlAhead - 1 && m < NS + NV; ++m) c += m < NS ? 1 : 2;
   return c;
 }
 
@@ -426,14 +455,19 @@ __global__ __launch_bounds__(256, 1) void bilinear_flash_kernel(FlashArgs args) 
   const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
   const int lr = lane / C::CPR;
   const unsigned vlane = (unsigned)(lr * C::RB + 16 * ((lane % C::CPR) ^ (C::RPP > 1 ? (lr << 2) : 0)));
+  // swizzle term of piece q: a permutation of q's low bits, hence u(PIECES * wave + i) = u(PIECES * wave) ^ u(i)
+  auto piece_u = [](int q) __attribute__((always_inline)) {
+    return C::RPP == 1 ? fl_swz(q) : (C::RPP == 2 ? (8 * (q & 1)) | ((q >> 1) & 3) : (q & 3));
+  };
+  const unsigned vlane_w = vlane ^ (unsigned)(16 * piece_u(C::PIECES * wave));
+  auto piece_voff = [&](int i) __attribute__((always_inline)) { return vlane_w ^ (unsigned)(16 * piece_u(i)); };
   auto issue_piece = [&](int t, int i) __attribute__((always_inline)) {
 #ifdef MI_STAMPS
     if ((args.diag & 1) && t >= 3) return;
 #endif
     const int q = C::PIECES * wave + i;
-    const int u = C::RPP == 1 ? fl_swz(q) : (C::RPP == 2 ? (8 * (q & 1)) | ((q >> 1) & 3) : (q & 3));
     const int stage = t & (kFlStages - 1);
-    fl_dma16(vlane ^ (unsigned)(16 * u), kv_base + (int64_t)t * C::STAGE + q * 1024, lds0 + stage * C::STAGE + q * 1024);
+    fl_dma16(piece_voff(i), kv_base + (int64_t)t * C::STAGE + q * 1024, lds0 + stage * C::STAGE + q * 1024);
   };
   auto issue_tile = [&](int t) __attribute__((always_inline)) {
 #pragma unroll
@@ -493,6 +527,7 @@ __global__ __launch_bounds__(256, 1) void bilinear_flash_kernel(FlashArgs args) 
   fl_static_for<0, C::NK>([&](auto KK) __attribute__((always_inline)) { fl_pin<(decltype(KK)::value < C::QA)>(qf[decltype(KK)::value]); });
   if constexpr (GRAD) fl_static_for<0, C::NT>([&](auto CT) __attribute__((always_inline)) { fl_pin_o<(decltype(CT)::value < C::OA)>(o[decltype(CT)::value]); });
 
+  constexpr bool kHeadInPv = GRAD && 2 * C::NT >= 32;  // enough output-product gaps to take the softmax head (D = 512)
   bf16x8 ring[kFlRing];
   bf16x8 pf[2];
   f32x16 s_prev, s_next;  // scores of the tile whose exponentials are due / of the tile being multiplied
@@ -501,7 +536,7 @@ __global__ __launch_bounds__(256, 1) void bilinear_flash_kernel(FlashArgs args) 
   // next tile's score product.  Slice 0 holds the (rare) general mask; every other slice is a handful of VALU ops.
   float tmax = MI_NEG_INF, off = 0.0f;
   constexpr int NSL = 32;
-  auto sm_slice = [&](auto SI, int tp) __attribute__((always_inline)) {
+  auto sm_slice = [&](auto SI, int tp, f32x16& s_prev) __attribute__((always_inline)) {  // (shadows the tile's name)
     constexpr int si = decltype(SI)::value;
 #ifdef MI_STAMPS
     if (args.diag & 2) return;
@@ -558,9 +593,12 @@ __global__ __launch_bounds__(256, 1) void bilinear_flash_kernel(FlashArgs args) 
 
   // ---- one loop iteration: [score product of tile tn = tp + 1 (HAS_S)] with the softmax slices of tile tp in its MFMA
   // gaps, then [output product of tile tp (HAS_V)] with the LDS-DMA pieces of tile tp + 3 in its gaps
-  auto iteration = [&](auto HAS_S_, auto HAS_V_, int tp) __attribute__((always_inline)) {
+  // HEAD_DONE: slices [0, 9) of tile tp (mask, tile maximum) already ran in the output-product gaps of the previous
+  // iteration (D = 512 with gradients: kHeadInPv) -- only the reference-point decision is left of the head.
+  auto iteration = [&](auto HAS_S_, auto HAS_V_, auto HEAD_DONE_, int tp) __attribute__((always_inline)) {
     constexpr bool HAS_S = decltype(HAS_S_)::value, HAS_V = decltype(HAS_V_)::value && GRAD;
     constexpr bool DO_SM = decltype(HAS_V_)::value;  // a finished tile is waiting for its exponentials
+    constexpr int H0 = decltype(HEAD_DONE_)::value ? 9 : 0;  // first slice still to run
     constexpr int NS = HAS_S ? C::NK : 0, NV = HAS_V ? 2 * C::NT : 0, NF = NS + NV;
     const int so = ((tp + 1) & (kFlStages - 1)) * C::STAGE + a0_lane;  // row reads of tile tp + 1
     const int vo = (tp & (kFlStages - 1)) * C::STAGE + a1_lane;       // transposed reads of tile tp
@@ -588,7 +626,7 @@ __global__ __launch_bounds__(256, 1) void bilinear_flash_kernel(FlashArgs args) 
     // shadow of the first fragment reads' LDS latency; the exponentials and the bf16 packing go one slice per MFMA gap.
     constexpr int HEAD = 10;
     if constexpr (DO_SM && HAS_S) {
-      fl_static_for<0, HEAD>([&](auto SI) __attribute__((always_inline)) { sm_slice(SI, tp); });
+      fl_static_for<H0, HEAD>([&](auto SI) __attribute__((always_inline)) { sm_slice(SI, tp, s_prev); });
       __builtin_amdgcn_sched_barrier(0);
     }
     // score product + the remaining softmax slices
@@ -600,22 +638,49 @@ __global__ __launch_bounds__(256, 1) void bilinear_flash_kernel(FlashArgs args) 
         constexpr int NSD = NS > 0 ? NS : 1;
         constexpr int per = (NSL - HEAD + NSD - 1) / NSD;  // slices per gap (1 at D = 512, 2 at 256, 3 at 128)
         constexpr int lo = HEAD + n * per, hi = (lo + per < NSL ? lo + per : NSL);
-        fl_static_for<(lo < NSL ? lo : NSL), hi>([&](auto SI) __attribute__((always_inline)) { sm_slice(SI, tp); });
+        fl_static_for<(lo < NSL ? lo : NSL), hi>([&](auto SI) __attribute__((always_inline)) { sm_slice(SI, tp, s_prev); });
       }
       __builtin_amdgcn_sched_barrier(0);
     });
-    if constexpr (DO_SM && !HAS_S) fl_static_for<0, NSL>([&](auto SI) __attribute__((always_inline)) { sm_slice(SI, tp); });
-    if constexpr (HAS_S && !HAS_V) fl_score_fence<true>(s_next);  // with an output product behind it the chain is long done
+    if constexpr (DO_SM && !HAS_S) fl_static_for<H0, NSL>([&](auto SI) __attribute__((always_inline)) { sm_slice(SI, tp, s_prev); });
+    if constexpr (HAS_S && !HAS_V) {
+      fl_score_fence<true>(s_next);  // with an output product behind it the chain is long done
+      // no output-product gaps to put the head of the new tile in: once, right here (the pipeline's first tile)
+      if constexpr (kHeadInPv) fl_static_for<0, 9>([&](auto SI) __attribute__((always_inline)) { sm_slice(SI, tp + 1, s_next); });
+    }
     // output product + LDS-DMA issue for tile tp + 3
     if constexpr (HAS_V) {
       constexpr int EVERY = NV / C::PIECES;
       const bool more = tp + 3 < nt;
+      // scalar bases of tile tp + 3 for this wave's pieces (uniform by construction; readfirstlane proves it to hipcc)
+      const uintptr_t gb = (uintptr_t)(kv_base + (int64_t)(tp + 3) * C::STAGE + wave * (C::PIECES * 1024));
+      const unsigned gb_lo = __builtin_amdgcn_readfirstlane((unsigned)gb);  // (the builtin returns int: keep the halves
+      const unsigned gb_hi = __builtin_amdgcn_readfirstlane((unsigned)(gb >> 32));  // unsigned, or the low one sign-extends)
+      const void* sb0 = (const void*)(((uintptr_t)gb_hi << 32) | gb_lo);
+      const void* sb1 = (const char*)sb0 + 4096;
+      const unsigned lb = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(((tp + 3) & (kFlStages - 1)) * C::STAGE) +
+                                                         (unsigned)(wave * (C::PIECES * 1024)));
       fl_static_for<0, NV>([&](auto UI) __attribute__((always_inline)) {
         constexpr int u = decltype(UI)::value, n = NS + u, ks = u / C::NT, ct = u % C::NT;
         fl_mfma_o<(ct < C::OA), (u % C::NT == 0), fl_wait_count<NS, NV>(n)>(o[ct], pf[ks], ring[n % kFlRing]);
         issue_read(std::integral_constant<int, n + kFlAhead>{});
+        if constexpr (HAS_S && kHeadInPv) {
+          // the next tile's scores are final (their chain ended >= 5 MFMAs ago): mask and maximum here, in gaps that
+          // carry no LDS-DMA piece, instead of at the head of the next iteration where nothing hides them
+          constexpr int hs = u == 5 ? 0 : u == 6 ? 1 : u == 8 ? 2 : u == 9 ? 3 : u == 10 ? 4 : u == 12 ? 5 : u == 13 ? 6
+                             : u == 14 ? 7 : u == 16 ? 8 : -1;
+          if constexpr (hs >= 0) sm_slice(std::integral_constant<int, hs>{}, tp + 1, s_next);
+        }
         if constexpr (u % EVERY == EVERY - 1) {
-          if (more) issue_piece(tp + 3, u / EVERY);
+          constexpr int i = u / EVERY;
+          if (more) {
+#ifdef MI_STAMPS
+            if (!(args.diag & 1))
+#endif
+            fl_dma16_at<(i & ~3) * 1024, (i & 3) * 1024,
+                        16 * (C::RPP == 1 ? fl_swz(i) : (C::RPP == 2 ? (8 * (i & 1)) | ((i >> 1) & 3) : (i & 3)))>(
+                vlane_w, i < 4 ? sb0 : sb1, lb);
+          }
         }
         __builtin_amdgcn_sched_barrier(0);
       });
@@ -629,7 +694,7 @@ __global__ __launch_bounds__(256, 1) void bilinear_flash_kernel(FlashArgs args) 
 
   if (nt > 0) {
     // tile 0's scores, nothing to overlap with yet (tp = -1: the "next" tile is tile 0)
-    iteration(T_{}, F_{}, -1);
+    iteration(T_{}, F_{}, F_{}, -1);
     fl_copy_scores(s_prev, s_next);
     for (int t = 0; t + 1 < nt; ++t) {
       if (t == nt / 2) MI_FL_STAMP(2);
@@ -642,12 +707,12 @@ __global__ __launch_bounds__(256, 1) void bilinear_flash_kernel(FlashArgs args) 
       if (t + 2 < nt) fl_wait_vmcnt_barrier<C::PIECES>();
       else fl_wait_vmcnt_barrier<0>();
       if (t == nt / 2) MI_FL_STAMP(3);
-      iteration(T_{}, T_{}, t);
+      iteration(T_{}, T_{}, std::integral_constant<bool, kHeadInPv>{}, t);
       fl_copy_scores(s_prev, s_next);
       if (t == nt / 2) MI_FL_STAMP(4);
     }
     MI_FL_STAMP(8);
-    iteration(F_{}, T_{}, nt - 1);
+    iteration(F_{}, T_{}, std::integral_constant<bool, kHeadInPv>{}, nt - 1);
   }
   MI_FL_STAMP(9);
 

@@ -32,21 +32,27 @@ __device__ __forceinline__ float wave_max_f(float v) {
   return v;
 }
 
-// absmax of up to three tensors (blockIdx.y selects one): float4 grid-stride loop, one atomicMax per workgroup
+// absmax of up to three tensors (blockIdx.y selects one): float4 grid-stride loop with four loads in flight per thread,
+// one atomicMax per workgroup (256 workgroups per tensor: more of them only queue up on the one address)
 struct AbsmaxJobs {
   const float* in[3];
   int64_t n[3];  // elements (multiples of 4; 16-byte aligned bases)
   Fp8Scales* sc;
   int slot[3];
 };
+constexpr int kAbsmaxBlocks = 256;
 static __global__ __launch_bounds__(256) void fp8_absmax_kernel(AbsmaxJobs J) {
   const int q = blockIdx.y;
-  const int64_t n4 = J.n[q] / 4;
+  const int64_t n4 = J.n[q] / 4, stride = (int64_t)gridDim.x * 256;
   const f32x4* p = reinterpret_cast<const f32x4*>(J.in[q]);
   float m = 0.0f;
-  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n4; e += (int64_t)gridDim.x * 256) {
-    const f32x4 v = p[e];
-    m = fmaxf(fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n4; e += 4 * stride) {
+    f32x4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = e + u * stride < n4 ? p[e + u * stride] : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      m = fmaxf(fmaxf(m, fmaxf(fabsf(v[u][0]), fabsf(v[u][1]))), fmaxf(fabsf(v[u][2]), fabsf(v[u][3])));
   }
   m = wave_max_f(m);
   __shared__ float part[4];

@@ -10,7 +10,8 @@ every bilinear_flash_kernel instantiation:
   * no instruction other than an MFMA accumulating into the same registers touches the destination of an MFMA issued
     fewer than WAIT_STATES wait states earlier (one per instruction, N + 1 per `s_nop N`);
   * no scratch (spill) instruction inside a loop;
-  * no `s_waitcnt vmcnt(0)` inside a loop (it would drain the LDS-DMA prefetch).
+  * no `s_waitcnt vmcnt(0)` inside a loop (it would drain the LDS-DMA prefetch);
+  * no compiler-generated instruction uses M0 (the loop's LDS-DMA pieces set M0 from asm without saving it).
 
 Exit status 0 = clean.  Used by tests/test_flash_isa_audit.py (CPU suite) and by hand after kernel edits.
 """
@@ -58,7 +59,14 @@ def audit(name, body):
     in_loop = False
     seen_mfma = False  # the prologue's id-copy loop legitimately waits for its plain loads
     lines = body.split("\n")
+    in_asm = False
     for ln, raw in enumerate(lines, 1):
+        if "#ASMSTART" in raw:
+            in_asm = True
+        elif "#ASMEND" in raw:
+            in_asm = False
+        elif not in_asm and re.search(r"\bm0\b", raw.split(";")[0]):
+            problems.append(f"{name}:{ln}: compiler-generated use of M0: {raw.strip()}")
         line = raw.split(";")[0].strip() if not raw.strip().startswith(";") else ""
         if "Loop Header" in raw or "in Loop:" in raw:
             in_loop = True
