@@ -138,8 +138,8 @@ static GemmBf16Args one_problem(const bf16_t* a, int64_t lda, const bf16_t* b, i
 
 // ------------------------------------------------------------------------------------------------ fast path
 static int fast_prep_and_t(const float* x, const float* y, const float* w, const int64_t* sid_rows,
-                           const int64_t* sid_cols, int64_t br, int64_t b, int64_t dx, int64_t dy, const BilinearPlan& p,
-                           hipStream_t st) {
+                           const int64_t* sid_cols, int64_t br, int64_t b, int64_t row_offset, int64_t dx, int64_t dy,
+                           const BilinearPlan& p, hipStream_t st) {
   // With the fused B x B kernel nobody reads Y^T or T^T any more; instead T and Y get a fragment-major copy (the
   // kernel's stationary operand, loaded straight into MFMA B fragments) and the equal-id tile flags ride along.
   if (p.fl.ok) {
@@ -148,7 +148,7 @@ static int fast_prep_and_t(const float* x, const float* y, const float* w, const
     side.j[0] = CvtJob{x, br, dx, nullptr, p.xtb, 0, 0, nullptr};
     side.j[1] = CvtJob{y, b, dy, p.yb, nullptr, 0, 0, p.yfb};
     side.j[2] = CvtJob{w, dx, dy, p.wb, nullptr, 0, 0, nullptr};
-    side.dup = DupFlagJob{sid_rows, sid_cols, (int)(br / 32), (int)(b / 32), p.fl_dup[0], p.fl_dup[1]};
+    side.dup = DupFlagJob{sid_rows, sid_cols, (int)(br / 32), (int)(b / 32), p.fl_dup[0], p.fl_dup[1], row_offset};
     const int rc1 = launch_prep_t(x, w, br, dy, dx, p.tb, p.tfb, side, st, "bilinear prep + T = X W");
     if (rc1 != MI_EINVAL) return rc1;
   }
@@ -158,7 +158,7 @@ static int fast_prep_and_t(const float* x, const float* y, const float* w, const
   jobs.j[0] = CvtJob{x, br, dx, p.xb, p.xtb, 0, 0, nullptr, ra, ra};
   jobs.j[1] = CvtJob{y, b, dy, p.yb, p.fl.ok ? nullptr : p.ytb, 0, 0, p.fl.ok ? p.yfb : nullptr, rb, rb};
   jobs.j[2] = CvtJob{w, dx, dy, p.wb, p.wtb, 0, 0, nullptr, rb, rb};
-  if (p.fl.ok) jobs.dup = DupFlagJob{sid_rows, sid_cols, (int)(br / 32), (int)(b / 32), p.fl_dup[0], p.fl_dup[1]};
+  if (p.fl.ok) jobs.dup = DupFlagJob{sid_rows, sid_cols, (int)(br / 32), (int)(b / 32), p.fl_dup[0], p.fl_dup[1], row_offset};
   int rc = launch_cvt_transpose3(jobs, st, "bilinear prep X Y W");
   if (rc) return rc;
   // T[i, c] = sum_a X[i, a] W[a, c]: A = Xb [br][dx], B = W^T [dy][dx]
@@ -189,7 +189,7 @@ static int bilinear_fwd_fast(const float* x, const float* y, const float* w, con
                              const int64_t* sid_cols, int64_t br, int64_t b, int64_t row_offset, int64_t dx, int64_t dy,
                              int estimator, int need_grad, float* loss_out, mi_stats* stats, float* partials_out,
                              float* scores_out, const BilinearPlan& p, hipStream_t st) {
-  int rc = fast_prep_and_t(x, y, w, sid_rows, sid_cols, br, b, dx, dy, p, st);
+  int rc = fast_prep_and_t(x, y, w, sid_rows, sid_cols, br, b, row_offset, dx, dy, p, st);
   if (rc) return rc;
   if (p.fl.ok) {
     rc = flash_stage(sid_rows, sid_cols, br, b, row_offset, dy, need_grad != 0, p, st);
@@ -544,7 +544,7 @@ int mi_bilinear_bwd(const float* x, const float* y, const float* w, const int64_
   }
   if (fast_ok(b_rows, b, d_img, d_txt, precision, w != nullptr)) {
     if (!workspace_from_forward) {  // rebuild the bf16 operand copies, T and the fused sums
-      rc = fast_prep_and_t(x, y, w, sid_rows, sid_cols, b_rows, b, d_img, d_txt, p, st);
+      rc = fast_prep_and_t(x, y, w, sid_rows, sid_cols, b_rows, b, row_offset, d_img, d_txt, p, st);
       if (rc) return rc;
       if (p.fl.ok) {
         rc = flash_stage(sid_rows, sid_cols, b_rows, b, row_offset, d_txt, true, p, st);
@@ -647,14 +647,15 @@ static SeparablePlan plan_separable(Workspace& ws, int64_t br, int64_t b, int64_
 }
 
 static int separable_prep_project(const float* x, const float* y, const float* wg, const float* wh,
-                                  const int64_t* sid_rows, const int64_t* sid_cols, int64_t br, int64_t b, int64_t dx,
-                                  int64_t dy, int64_t k, const SeparablePlan& p, hipStream_t st) {
+                                  const int64_t* sid_rows, const int64_t* sid_cols, int64_t br, int64_t b,
+                                  int64_t row_offset, int64_t dx, int64_t dy, int64_t k, const SeparablePlan& p,
+                                  hipStream_t st) {
   CvtJobs jobs{};
   jobs.j[0] = CvtJob{x, br, dx, p.xb, p.xtb, 0, 0, nullptr};
   jobs.j[1] = CvtJob{y, b, dy, p.yb, p.ytb, 0, 0, nullptr};
   jobs.j[2] = CvtJob{wg, dx, k, p.gb, p.gtb, 0, 0, nullptr};
   jobs.j[3] = CvtJob{wh, dy, k, p.hb, p.htb, 0, 0, nullptr};
-  jobs.dup = DupFlagJob{sid_rows, sid_cols, (int)(br / 32), (int)(b / 32), p.dup[0], p.dup[1]};
+  jobs.dup = DupFlagJob{sid_rows, sid_cols, (int)(br / 32), (int)(b / 32), p.dup[0], p.dup[1], row_offset};
   int rc = launch_cvt_transpose3(jobs, st, "separable prep X Y Wg Wh");
   if (rc) return rc;
   // A[i, c] = sum_a X[i, a] Wg[a, c] (A operand Xb [br][dx], B operand Wg^T [k][dx]);  C likewise from Y, Wh
@@ -715,7 +716,7 @@ int mi_separable_fwd(const float* x, const float* y, const float* wg, const floa
   }
   hipStream_t st = (hipStream_t)stream;
   if (p.fast) {
-    rc = separable_prep_project(x, y, wg, wh, sid_rows, sid_cols, b_rows, b, d_img, d_txt, d_proj, p, st);
+    rc = separable_prep_project(x, y, wg, wh, sid_rows, sid_cols, b_rows, b, row_offset, d_img, d_txt, d_proj, p, st);
     if (rc) return rc;
     rc = separable_flash(sid_rows, sid_cols, b_rows, b, row_offset, d_proj, need_grad != 0, p, st);
     if (rc) return rc;
@@ -762,7 +763,7 @@ int mi_separable_bwd(const float* x, const float* y, const float* wg, const floa
   const int64_t br = b_rows, k = d_proj;
   if (p.fast) {
     if (!workspace_from_forward) {
-      rc = separable_prep_project(x, y, wg, wh, sid_rows, sid_cols, br, b, d_img, d_txt, k, p, st);
+      rc = separable_prep_project(x, y, wg, wh, sid_rows, sid_cols, br, b, row_offset, d_img, d_txt, k, p, st);
       if (rc) return rc;
       rc = separable_flash(sid_rows, sid_cols, br, b, row_offset, k, true, p, st);
       if (rc) return rc;

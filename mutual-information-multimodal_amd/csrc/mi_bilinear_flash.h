@@ -80,6 +80,7 @@ struct FlashArgs {
   int diag;     // diagnostic (MI_STAMPS) builds only, timing experiments with WRONG results: bit 0 no LDS-DMA in the loop,
                 // bit 1 no softmax slices, bit 2 no workgroup barrier in the loop (MI_FLASH_DIAG in the environment)
   int slab_f16; // 1: scaled fp16 slabs (see FlashProblem::slab)
+  int no_index_mask;  // A/B switch MI_FLASH_NO_INDEX_MASK: diagonal-only tiles take the exact id compares as well
 };
 
 template <int D>
@@ -438,11 +439,14 @@ __global__ __launch_bounds__(256, 1) void bilinear_flash_kernel(FlashArgs args) 
   MI_FL_STAMP(11);
   // which streamed tiles hold a pair with equal study ids for this wave's rows (bit t: tile tile0 + t); the diagonal is
   // such a pair, so the positives only ever show up in flagged tiles
-  unsigned long long dupmask;
+  unsigned long long dupmask, diagmask;
   {
+    // flag 2: some pair of the tile shares a study id off the main diagonal -> exact id compares; flag 1: the tile's main
+    // diagonal pairs this wave's samples with themselves and nothing else matches -> mask by index
     const unsigned char* df = P.dup + (wave_active ? m_wave / 32 : 0) * n_tiles_all + tile0;
-    const bool flag = lane < nt ? df[lane] != 0 : false;
-    dupmask = __ballot(flag);
+    const int flag = lane < nt ? (int)df[lane] : 0;
+    dupmask = __ballot(flag == 2 || (flag == 1 && args.no_index_mask));
+    diagmask = __ballot(flag == 1 && !args.no_index_mask);
   }
 
   // ---- LDS-DMA pieces of this wave: piece q = PIECES * wave + i covers tile rows [q * RPP, (q + 1) * RPP).  Lane l
@@ -522,7 +526,7 @@ __global__ __launch_bounds__(256, 1) void bilinear_flash_kernel(FlashArgs args) 
   MI_FL_STAMP(1);
   // first "use" of the plain loads here, so that hipcc places their vmcnt wait in the prologue and not at the first
   // compare of the general mask path inside the loop (where it would drain the LDS-DMA prefetch)
-  asm volatile("" ::"v"(sid_i), "s"(dupmask));
+  asm volatile("" ::"v"(sid_i), "s"(dupmask), "s"(diagmask));
   // pin the register classes once: from here on only the asm MFMAs touch these values
   fl_static_for<0, C::NK>([&](auto KK) __attribute__((always_inline)) { fl_pin<(decltype(KK)::value < C::QA)>(qf[decltype(KK)::value]); });
   if constexpr (GRAD) fl_static_for<0, C::NT>([&](auto CT) __attribute__((always_inline)) { fl_pin_o<(decltype(CT)::value < C::OA)>(o[decltype(CT)::value]); });
@@ -543,6 +547,7 @@ __global__ __launch_bounds__(256, 1) void bilinear_flash_kernel(FlashArgs args) 
 #endif
     if constexpr (si == 0) {
       if (__builtin_amdgcn_readfirstlane((int)((dupmask >> tp) & 1ull))) {
+        MI_FL_STAMP(5);
         // some pair of this tile shares a study id (always so on the diagonal): exact 64-bit compares, positives
         const int64_t* sl = reinterpret_cast<const int64_t*>(smem + C::SID_OFF) + tp * kFlBN + 4 * half;
         const int d0 = d0_wave - tp * kFlBN;  // streamed row (inside this tile) of stationary row 0's positive
@@ -551,12 +556,26 @@ __global__ __launch_bounds__(256, 1) void bilinear_flash_kernel(FlashArgs args) 
 #pragma unroll
           for (int r = 0; r < 16; ++r) pos += (want == (r & 3) + 8 * (r >> 2)) ? s_prev[r] : 0.0f;
         }
+        MI_FL_STAMP(7);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const bool neg = sl[(r & 3) + 8 * (r >> 2)] != sid_i;
           cnt += (unsigned)__popcll(__ballot(neg));
           s_prev[r] = neg ? s_prev[r] : MI_NEG_INF;
         }
+        MI_FL_STAMP(6);
+      } else if (__builtin_amdgcn_readfirstlane((int)((diagmask >> tp) & 1ull))) {
+        // the tile's main diagonal holds this wave's 32 positives and no other pair is masked: streamed row r32 - 4 half
+        // of the lane's column ... i.e. accumulator element (r & 3) + 8 (r >> 2) == r32 - 4 half.  No id loads, a third
+        // of the general path's instructions (whose cold instruction fetch alone cost ~5,000 cycles per occurrence).
+        const int want = r32 - 4 * half;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const bool p = want == (r & 3) + 8 * (r >> 2);
+          pos += p ? s_prev[r] : 0.0f;
+          s_prev[r] = p ? MI_NEG_INF : s_prev[r];
+        }
+        cnt += 1024u - 32u;
       } else {
         cnt += 1024u;
       }
@@ -726,6 +745,9 @@ __global__ __launch_bounds__(256, 1) void bilinear_flash_kernel(FlashArgs args) 
   }
   if constexpr (GRAD) {
     fl_mfma_drain_all();
+    // tie every accumulator to a statement BEHIND the drain: hipcc is free to hoist a plain read of o[] above an asm that
+    // does not name it (the audit caught a v_accvgpr_read 16 wait states after the last MFMA at D = 256)
+    fl_static_for<0, C::NT>([&](auto CT) __attribute__((always_inline)) { fl_pin_o<(decltype(CT)::value < C::OA)>(o[decltype(CT)::value]); });
     const int64_t wv = ((int64_t)split * P.n_rb + rb) * 4 + wave;
     if (wave_active && args.slab_f16) {
       // one power-of-two scale per wave: the largest |element| lands in [2^13, 2^14), fp16's range is never left and
@@ -1038,6 +1060,8 @@ static inline int launch_flash(FlashArgs a, int64_t d, bool grad, hipStream_t st
 #ifdef MI_STAMPS
   if (const char* e = getenv("MI_FLASH_DIAG")) a.diag = atoi(e);
 #endif
+  static const int no_index_mask = getenv("MI_FLASH_NO_INDEX_MASK") ? 1 : 0;  // A/B switch
+  a.no_index_mask = no_index_mask;
   static const int xcd_rows = getenv("MI_FLASH_XCD_COMBO") ? 0 : 1;  // A/B switch
   a.xcd_rows = xcd_rows;
   int max_rb = a.p[0].n_rb;

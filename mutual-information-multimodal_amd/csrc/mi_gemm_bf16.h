@@ -1413,14 +1413,17 @@ struct DupFlagJob {
   int na, nb;              // 32-row blocks of the two id lists; na == 0: no job
   unsigned char* flag;     // [na][nb]
   unsigned char* flag_t;   // [nb][na]
+  int64_t row_offset;      // global index of local row 0: pair (i, j) is a sample with itself iff j == i + row_offset
 };
 struct CvtJobs {
   CvtJob j[4];     // blockIdx.z = 0..3 (unused jobs have R == 0)
   DupFlagJob dup;  // blockIdx.z = 4
 };
 
-// flag[a][b] = 1 iff some image row of block a and some text row of block b share a study id.  One call handles the 64
-// column blocks starting at b0 for row block a (256 threads: 4 per column block, 8 rows each); exact 64-bit compares.
+// flag[a][b]: 0 = no image row of block a shares a study id with a text row of block b; 1 = the only such pairs are the
+// 32 samples paired with themselves on the block's main diagonal (the fused kernel then masks by index, no id compares);
+// 2 = anything else (exact id compares in the kernel).  One call handles the 64 column blocks starting at b0 for row
+// block a (256 threads: 4 per column block, 8 rows each); exact 64-bit compares.
 __device__ __forceinline__ void dup_flags_block(const DupFlagJob& J, int a, int b0, int64_t* rows_lds) {
   const int tid = threadIdx.x;
   if (tid < 32) rows_lds[tid] = J.sid_rows[a * 32 + tid];
@@ -1431,16 +1434,23 @@ __device__ __forceinline__ void dup_flags_block(const DupFlagJob& J, int a, int 
 #pragma unroll
     for (int e = 0; e < 8; ++e) mine[e] = rows_lds[8 * q + e];
     const int64_t* c = J.sid_cols + (int64_t)b * 32;
-    bool any = false;
+    // the block's main diagonal pairs samples with themselves iff the diagonal of the pair matrix runs through it aligned
+    const bool diag_block = (J.row_offset & 31) == 0 && (int64_t)b * 32 == (int64_t)a * 32 + J.row_offset;
+    bool any = false, other = false;
 #pragma unroll 8
     for (int j = 0; j < 32; ++j) {
       const int64_t v = c[j];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) any |= v == mine[e];
+      for (int e = 0; e < 8; ++e) {
+        const bool eq = v == mine[e];
+        any |= eq;
+        other |= eq && !(diag_block && j == 8 * q + e);
+      }
     }
-    int f = any ? 1 : 0;
+    int f = other ? 2 : (any ? 1 : 0);
     f |= __shfl_xor(f, 1);
     f |= __shfl_xor(f, 2);
+    f = (f & 2) ? 2 : f;  // (1 | 2 = 3)
     if (q == 0) {
       J.flag[(int64_t)a * J.nb + b] = (unsigned char)f;
       J.flag_t[(int64_t)b * J.na + a] = (unsigned char)f;

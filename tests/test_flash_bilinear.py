@@ -175,3 +175,39 @@ def test_flash_row_blocks_equal_full_batch(dev, b, d, G):
     ob = orc.bilinear_step_rounded(x, y, w, sid, "infonce", row_block=(br, 2 * br))
     _, c1, _ = ops.backward(saved[1], stats, go)
     assert _rel(c1.cpu(), ob["dy"]) < 1e-2
+
+
+def test_flash_unaligned_row_offset_and_flag_values(dev):
+    """A row block whose offset is NOT a multiple of 32: the diagonal of the pair matrix then cuts through the 32 x 32
+    tiles instead of lying on their main diagonals, the tile flags must say "general" (2) there and the kernel must take
+    the exact id compares.  Three blocks [16, 80), [80, 144), [144, 208) of a batch of 256 (rows 0..15 and 208..255 are
+    columns only); the merged statistics and the summed dX / dY / dW are checked against the oracle restricted to those
+    rows."""
+    from mutual_info_img_txt.distributed import HipBilinearOps
+    from mutual_info_img_txt import _hip
+    b, d, br, off0 = 256, 128, 64, 16
+    gen = torch.Generator().manual_seed(99)
+    x = torch.randn(b, d, generator=gen)
+    y = torch.randn(b, d, generator=gen)
+    w = torch.randn(d, d, generator=gen) * (0.25 / math.sqrt(d))
+    sid = torch.arange(b)
+    sid[40] = sid[41]
+    ops = HipBilinearOps()
+    xd, yd, wd, sd = x.to(dev), y.to(dev), w.to(dev), sid.to(dev)
+    rows = list(range(off0, off0 + 3 * br))
+    recs, saved = [], []
+    for g in range(3):
+        lo = off0 + g * br
+        rec, sv = ops.forward(xd[lo:lo + br].contiguous(), yd, [wd], sd[lo:lo + br].contiguous(), sd, lo, 1, 1, True)
+        recs.append(rec)
+        saved.append(sv)
+    # the oracle on the same rows: scores of rows [16, 208) against all columns
+    o = orc.bilinear_step_rounded(x, y, w, sid, "infonce")
+    s = o["scores"][rows]
+    neg = orc.negative_mask(sid)[rows]
+    lse = torch.logsumexp(s[neg], dim=0)
+    pos = torch.stack([s[k, rows[k]] for k in range(len(rows))]).mean()
+    loss, stats = ops.merge(torch.stack(recs), len(rows), 1)
+    st = _hip.stats_dict(stats)
+    assert st["n_neg"] == int(neg.sum())
+    assert abs(float(loss) - float(lse - pos)) < 2e-3 * float(s.abs().max())

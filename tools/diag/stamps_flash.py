@@ -56,3 +56,22 @@ print("--- one pipelined iteration (t = nt/2)")
 seg("wait + barrier", 2, 3)
 seg("scores(t+1) | softmax(t) | output(t)", 3, 4)
 print(f"kernel span {s[:,10].max()-s[:,0].min()} ticks")
+# who is slow?  (the launch ends with its slowest workgroup).  Workgroup L runs on XCD L % 8; with the row-block mapping
+# unit = L % 8 + 8 * ((L // 8) // 4), split = (L // 8) % 4, problem 0 for the first b / 128 units
+full = buf.cpu().numpy().reshape(-1, 16)
+idx = np.nonzero(full[:, 0] != 0)[0]
+loop = full[idx, 8] - full[idx, 1]
+whole = full[idx, 10] - full[idx, 0]
+n_rb = b // 128
+for name, key in (("XCD", idx % 8), ("split", (idx // 8) % 4), ("problem", ((idx % 8) + 8 * ((idx // 8) // 4)) // n_rb)):
+    print(f"loop cycles by {name}:", {int(k): int(np.median(loop[key == k])) for k in np.unique(key)})
+order = np.argsort(whole)[::-1][:8]
+print("slowest workgroups (L, xcd, split, whole, loop):", [(int(idx[o]), int(idx[o] % 8), int((idx[o] // 8) % 4), int(whole[o]), int(loop[o])) for o in order])
+g = full[idx]
+has = g[:, 5] != 0
+if has.any():
+    d56 = g[has, 6] - g[has, 5]
+    print(f"general mask path of wave 0 (slots 5 -> 6): {int(has.sum())} workgroups, median {np.median(d56):.0f} cycles, max {d56.max()}")
+    print("loop of workgroups whose wave 0 took it vs not:", int(np.median(loop[has])), int(np.median(loop[~has])))
+    if (g[has, 7] != 0).all():
+        print(f"   positives block (5 -> 7) median {np.median(g[has, 7] - g[has, 5]):.0f}, id compares (7 -> 6) median {np.median(g[has, 6] - g[has, 7]):.0f}")
