@@ -194,24 +194,12 @@ __global__ __launch_bounds__(256 * NWN, 2) void concat_fwd_dma_kernel(
 #pragma unroll
       for (int a = 0; a < 4; ++a) {
         unsigned nword = 0u;
-        // the 16 output weights of this lane's hidden units, loaded up front as four 16-byte reads (units (r & 3) + 8 (r >> 2)
-        // + 4 h of the 32-unit group).  Written as `pos ? z * w3[nl] : 0` hipcc made every one of them a conditional LDS
-        // load of its own (save exec, ds_read_b32, wait, restore): 128 serialised LDS round trips per pass, about as long
-        // as the pass's 512 MFMAs.
-        __builtin_amdgcn_sched_barrier(0);  // one group's weights live at a time (the accumulators fill the file)
-        float w3r[16];
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const f32x4 wq = *reinterpret_cast<const f32x4*>(&w3s[wn * 128 + a * 32 + 8 * g + 4 * h]);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) w3r[4 * g + e] = wq[e];
-        }
         static_for<16>([&](auto rc) {
           constexpr int r = decltype(rc)::value;
+          const int nl = wn * 128 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
           const float z = acc[a][t][r];
           const bool pos = z > 0.0f;
-          const float zw = z * w3r[r];
-          s += pos ? zw : 0.0f;
+          s += pos ? z * w3s[nl] : 0.0f;
           if (bitsP) {
             pbits |= (unsigned long long)(pos ? 1u : 0u) << (16 * a + r);
             const unsigned long long bal = __ballot(pos);
