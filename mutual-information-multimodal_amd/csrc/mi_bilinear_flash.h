@@ -509,7 +509,8 @@ __global__ __launch_bounds__(256, 1) void bilinear_flash_kernel(FlashArgs args) 
   float mref = MI_NEG_INF;         // wave-uniform reference point of the exponentials
   constexpr float kLog2e = 1.4426950408889634f;
 
-  // per-lane constants of the fragment addresses (derivations: DESIGN.md section 4)
+  // per-lane constants of the fragment addresses (derivation: DESIGN.md section 4.1, "Fragment addressing"; the same
+  // formulas restated in numpy and checked end to end: tests/test_flash_addressing.py)
   const int fxh = half ^ fl_swz(r32);                       // row read: chunk (2 kk + half) ^ swz(row)
   const int a0_lane = r32 * C::RB + 16 * fxh;
   const int g16 = lane >> 4, q4 = (lane & 15) >> 2, p4 = lane & 3;
