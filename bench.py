@@ -356,6 +356,11 @@ def cpu_baseline(kind, args):
 
 def main():
     args = parse_args()
+    # The contract is ONE JSON line on stdout.  Libraries print there too (RCCL writes its version banner to stdout when
+    # the first communicator is made): keep the real stdout aside and point fd 1 at stderr for the rest of the run.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -481,7 +486,8 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
 
 
 if __name__ == "__main__":
