@@ -1732,7 +1732,7 @@ static __global__ __launch_bounds__(256, 2) void bilinear_prep_t_kernel(PrepTArg
 static inline int launch_prep_t(const float* x, const float* w, int64_t m, int64_t n, int64_t k, bf16_t* tb, bf16_t* tfb,
                                 const CvtJobs& jobs, hipStream_t st, const char* what) {
   static const bool off = getenv("MI_NO_PREP_T") != nullptr;  // A/B switch: separate conversion and GEMM launches
-  if (off || k % 64 != 0 || n % kTile != 0 || m < 1 || (uintptr_t)x % 16 != 0 || (uintptr_t)w % 4 != 0 ||
+  if (off || k % 64 != 0 || n % kTile != 0 || m < 1 || (uintptr_t)x % 16 != 0 || (uintptr_t)w % 16 != 0 ||
       (uintptr_t)tb % 16 != 0 || (tfb && (m % 32 != 0 || (uintptr_t)tfb % 16 != 0)))
     return MI_EINVAL;
   PrepTArgs a{};
