@@ -875,6 +875,17 @@ __global__ __launch_bounds__(256) void flash_reduce_kernel(FlashReduceArgs args)
   float acc[16];
 #pragma unroll
   for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
+  // the rows subtracted on the diagonal are known now: their loads go out with the slabs', not after the first barrier
+  const int64_t i0 = wb * 32;
+  const int64_t c0 = (int64_t)cc * 128;
+  const int orow = tid >> 3, ocs = (tid & 7) * 16;
+  const int64_t ojo = i0 + orow + J.diag;
+  const bool has_other = ojo >= 0 && ojo < J.n_other;
+  bf16x8 oth_a = {}, oth_b = {};
+  if (has_other) {
+    oth_a = *reinterpret_cast<const bf16x8*>(J.other + ojo * D + c0 + ocs);
+    oth_b = *reinterpret_cast<const bf16x8*>(J.other + ojo * D + c0 + ocs + 8);
+  }
   const f16_t* slab16 = reinterpret_cast<const f16_t*>(J.slab);
   const float* unscale = reinterpret_cast<const float*>(slab16 + (int64_t)J.n_split * J.n_rb * 4 * (32 * D));
   // four splits per round: their loads are independent and issued together, the additions keep the split order.  A wave
@@ -948,22 +959,18 @@ __global__ __launch_bounds__(256) void flash_reduce_kernel(FlashReduceArgs args)
     }
   }
   __syncthreads();
-  const int64_t i0 = wb * 32;
-  const int64_t c0 = (int64_t)cc * 128;
   {
     // row-major outputs: thread -> row tid >> 3, 16 columns
-    const int row = tid >> 3, cs = (tid & 7) * 16;
-    const int64_t i = i0 + row, jo = i + J.diag;
+    const int row = orow, cs = ocs;
+    const int64_t i = i0 + row;
     float v[16];
 #pragma unroll
     for (int e = 0; e < 16; ++e) v[e] = tile[row][cs + e];
-    if (jo >= 0 && jo < J.n_other) {
-      const bf16x8 a = *reinterpret_cast<const bf16x8*>(J.other + jo * D + c0 + cs);
-      const bf16x8 b = *reinterpret_cast<const bf16x8*>(J.other + jo * D + c0 + cs + 8);
+    if (has_other) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        v[e] -= gpos * (float)a[e];
-        v[8 + e] -= gpos * (float)b[e];
+        v[e] -= gpos * (float)oth_a[e];
+        v[8 + e] -= gpos * (float)oth_b[e];
       }
 #pragma unroll
       for (int e = 0; e < 16; ++e) tile[row][cs + e] = v[e];  // the transposed output reads the tile again
