@@ -9,13 +9,15 @@ Headline workload (BASELINE.json configs[3], the configuration its metric is quo
   batch is sharded by row blocks (strong scaling) and the text embeddings are all-gathered over RCCL.
 A step = pair enumeration + scorer + bound + ALL gradients (dX, dY, d theta) through the product API
 `graphed.GraphedMiStep` (one GPU) / `distributed.GlobalBatchGraphStep` (N GPUs): the C-ABI launches of the step,
-replayed from hipGraphs (`--graph off`: issued one by one).  Encoders, optimisers and data loading are not in the metric.
+issued as direct calls or replayed from hipGraphs (`--graph auto`, the default, times both during warm-up and keeps the
+faster; `--graph on|off` forces one).  Encoders, optimisers and data loading are not in the metric.
 
 One JSON line on stdout (rank 0): the driver's contract (`value` from exactly K steps between barriers / synchronize),
 plus `timing` (median / p10 / p90 of >= 50 individually hipEvent-timed steps, graph and eager), `roofline` (dominant
-kernel, HIP-event timed through the library's profiling hook), `parity_mode` (the same step in the fp32 parity mode),
-`secondary` (the reference's own critic, make_mlp(2d,[1024,512])) and `cpu_baseline` (the oracle timed on this box's
-host cores, rank 0, N = 1 only).
+kernel, HIP-event timed through the library's profiling hook; measured HBM bytes and matrix-pipe busy fraction from the
+newest committed PMC pass of the SAME kernel sources), `parity_mode` (the same step in the modes held to fp32 tolerances:
+"f32" and "bf16x3"), `fp8_mode` (BASELINE configs[4] on one GPU: B = 8192, d = 1024), `secondary` (the reference's own
+critic, make_mlp(2d,[1024,512])) and `cpu_baseline` (the oracle timed on this box's host cores, rank 0, N = 1 only).
 """
 import argparse
 import glob
