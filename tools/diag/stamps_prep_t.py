@@ -48,14 +48,4 @@ dur = C[:, 5] - C[:, 0]
 print(f"conversion blocks: duration median {np.median(dur):.0f} p90 {np.percentile(dur,90):.0f};  start median {np.median(C[:,0]-t0):.0f} p90 {np.percentile(C[:,0]-t0,90):.0f} max {np.max(C[:,0]-t0):.0f};  last end {np.max(C[:,5]-t0):.0f}")
 hist, edges = np.histogram(C[:, 0] - t0, bins=8)
 print("conversion block start histogram:", list(zip(edges[:-1].astype(int).tolist(), hist.tolist())))
-# s_memtime is per XCD: look at ONE XCD's timeline (workgroup L runs on XCD L % 8)
-full = buf.cpu().numpy().reshape(-1, 8)
-idx = np.nonzero(full[:, 0] != 0)[0]
-for xcd in (0, 3):
-    sel = idx[idx % 8 == xcd]
-    g = full[sel]
-    z = g[:, 0].min()
-    is_t = sel < n_t
-    print(f"XCD {xcd}: span {g[:, 5].max() - z} cycles; T tiles end at {sorted((g[is_t, 5] - z).tolist())[-3:]} (last three); "
-          f"conversion blocks: last start {int((g[~is_t, 0] - z).max())}, last end {int((g[~is_t, 5] - z).max())}; "
-          f"blocks: {int(is_t.sum())} T + {int((~is_t).sum())} conversion")
+# (s_memtime values are only comparable within one workgroup: durations above, no absolute timeline)
