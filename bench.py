@@ -144,6 +144,12 @@ class Stepper:
         self.graph_used = bool(graph)
         self.use_eager = not graph
         self.launch_probe_ms = None
+        if self.dist_mode and args.graph == "auto":
+            # between RCCL calls a replay only adds its fixed cost: measured with one rank through the RCCL path, direct
+            # calls 0.183 ms / step against 0.197 ms for the two replays.  No per-rank probe (all ranks must agree).
+            graph = False
+            self.graph_used = False
+            self.use_eager = True
         if self.dist_mode:
             from mutual_info_img_txt.distributed import GlobalBatchGraphStep
             from mutual_info_img_txt.mi_critics import _concat_params
