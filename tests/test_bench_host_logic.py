@@ -1,0 +1,39 @@
+"""Host-side logic of bench.py that needs no GPU: the algorithmic flop counts behind `roofline.achieved`, the source
+fingerprint that decides whether a committed PMC pass may be attached, and the refusal of a stale pass."""
+import json
+
+import bench
+
+
+def test_algorithmic_flops_match_design():
+    b, d = 4096, 512
+    # fused B x B launch: scores + two gradient contractions, no credit for the recomputed score product
+    assert bench.kernel_flops("bilinear fused S | P Y | P^T T", b, b, d, d) == 6.0 * b * b * d
+    # whole step: three B x B x d products and three B x d x d products, 2 flops per multiply-add
+    assert bench.algorithmic_flops("bilinear", b, d, d) == 6.0 * b * b * d + 6.0 * b * d * d
+    assert bench.PEAK_TFLOPS["bf16"] == 2500.0 and bench.PEAK_TFLOPS["f32"] == 157.3
+
+
+def test_committed_pmc_pass_belongs_to_these_sources():
+    """profiles/*_pmc_traffic.json of the newest round must have been taken on the kernel sources in the tree (otherwise
+    `roofline.traffic` silently goes null in the judged bench line)."""
+    c = bench.measured_counters("bilinear fused S | P Y | P^T T", 4096, 512)
+    assert c is not None and not c.get("stale"), c
+    assert abs(c["bytes"] - (c["fetch"] + c["write"])) <= 2 and 0.0 < c["mfma_busy_frac"] < 1.0  # (each is rounded)
+    assert bench.measured_counters("bilinear fused S | P Y | P^T T", 2048, 512) is None  # only the profiled configuration
+
+
+def test_stale_pmc_pass_is_refused(tmp_path, monkeypatch):
+    root = tmp_path / "repo"
+    (root / "profiles").mkdir(parents=True)
+    doc = {"csrc_sha": "0" * 12, "kernels": {"void mi::bilinear_flash_kernel<512, true>(mi::FlashArgs) grid=1":
+                                              {"fetch_bytes": 1.0, "write_bytes": 2.0, "total_bytes": 3.0}}}
+    (root / "profiles" / "zz_pmc_traffic.json").write_text(json.dumps(doc))
+    monkeypatch.setattr(bench, "ROOT", str(root))
+    c = bench.measured_counters("bilinear fused S | P Y | P^T T", 4096, 512)
+    assert c == {"stale": True, "source": "zz_pmc_traffic.json",
+                 "note": "PMC pass predates the current kernel sources: not attached"}
+    doc["csrc_sha"] = bench.csrc_sha()
+    (root / "profiles" / "zz_pmc_traffic.json").write_text(json.dumps(doc))
+    c = bench.measured_counters("bilinear fused S | P Y | P^T T", 4096, 512)
+    assert c["bytes"] == 3 and c["source"] == "zz_pmc_traffic.json"
