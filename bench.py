@@ -1,7 +1,10 @@
 #!/usr/bin/env python3
 """Benchmark of the MI-critic hot path: one critic forward + backward over a synthetic batch per step.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W]          (N > 1: launched by torch.distributed.run, one rank/GPU)
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+      N > 1: either launched by torch.distributed.run (one rank per GPU; RANK / LOCAL_RANK / WORLD_SIZE from the
+      environment) or, when WORLD_SIZE is not set, bench.py starts the N ranks itself as child processes and relays
+      rank 0's line; --gpus must equal the number of ranks, anything else is an error
 
 Headline workload (BASELINE.json configs[3], the configuration its metric is quoted on; it fits one GPU):
   global-batch "InfoNCE" (reference semantics, mi_critics.py:14-23), bilinear critic S = (X W) Y^T, B_global = 4096,
@@ -69,7 +72,57 @@ def parse_args():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-seconds", type=float, default=15.0)
     p.add_argument("--profile-steps", type=int, default=5)
+    p.add_argument("--master-port", type=int, default=0, help="rendezvous port when bench.py starts its own ranks")
+    p.add_argument("--rendezvous-only", action="store_true",
+                   help="start the ranks, form the process group (backend: MI_BENCH_BACKEND, default nccl), all-reduce one "
+                        "number and print {world, sum}: the launcher's own test (runs under gloo without a GPU)")
     return p.parse_args()
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment: start N ranks of this same script
+    (one per GPU) under torch.distributed.run -- as CHILD processes, before this process has touched the GPU (a process
+    that has initialised HIP must not exec or fork GPU work on this pool) -- relay rank 0's JSON line and the exit code."""
+    import socket
+    import subprocess
+    port = args.master_port
+    if not port:
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE)
+    out = proc.stdout.decode(errors="replace")
+    lines = [ln for ln in out.splitlines() if ln.startswith("{")]
+    if proc.returncode != 0 or not lines:
+        sys.stderr.write(out)
+        sys.stderr.write(f"bench.py: the {args.gpus}-rank run failed (exit code {proc.returncode}); no result line\n")
+        raise SystemExit(proc.returncode or 1)
+    sys.stdout.write(lines[-1] + "\n")
+    sys.stdout.flush()
+    raise SystemExit(0)
+
+
+def rendezvous_only(args, world, rank):
+    backend = os.environ.get("MI_BENCH_BACKEND", "nccl")
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    if backend == "nccl":
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+        dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+    else:
+        dev = torch.device("cpu")
+    dist.init_process_group(backend, rank=rank, world_size=world)
+    t = torch.tensor([float(rank + 1)], device=dev)
+    dist.all_reduce(t)
+    dist.barrier()
+    if rank == 0:
+        print(json.dumps({"world": dist.get_world_size(), "gpus_arg": args.gpus, "sum": float(t.item()), "backend": backend}),
+              flush=True)
+    dist.destroy_process_group()
 
 
 # ------------------------------------------------------------------------------------------------------------
@@ -364,6 +417,17 @@ def cpu_baseline(kind, args):
 
 def main():
     args = parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        launch_ranks(args)  # does not return
+    world_env = int(os.environ.get("WORLD_SIZE", "1"))
+    if world_env != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world_env}: launch with "
+                         f"`python bench.py --gpus N` (starts its own ranks) or torch.distributed.run --nproc-per-node N "
+                         f"bench.py --gpus N")
+    if args.rendezvous_only:
+        return rendezvous_only(args, world_env, int(os.environ.get("RANK", "0")))
     # The contract is ONE JSON line on stdout.  Libraries print there too (RCCL writes its version banner to stdout when
     # the first communicator is made): keep the real stdout aside and point fd 1 at stderr for the rest of the run.
     sys.stdout.flush()

@@ -244,13 +244,34 @@ class TextBert(nn.Module):
 
     @classmethod
     def from_pretrained(cls, pretrained_dir, config):
+        """Weights from ``<pretrained_dir>/pytorch_model.bin`` (reference model.py:104 through
+        ``BertPreTrainedModel.from_pretrained``, which raises when the file is absent and redirects a bare ``BertModel``
+        checkpoint into ``model.bert`` by its base-model prefix).  A missing file or a checkpoint that fills no ``bert.*``
+        parameter is an error: random initialisation is an explicit choice (``TextBert(config)``), never a fall-back."""
         model = cls(config)
         path = os.path.join(pretrained_dir, JOINT_MODEL_FILE)
-        if os.path.isfile(path):
-            state = convert_legacy_keys(torch.load(path, map_location='cpu', weights_only=True))
-            info = model.load_state_dict(state, strict=False)
-            logging.getLogger(__name__).info("TextBert.from_pretrained: missing %s unexpected %s", info.missing_keys,
-                                             info.unexpected_keys)
+        if not os.path.isfile(path):
+            raise FileNotFoundError(f"TextBert.from_pretrained: no weights file {path} (construct TextBert(config) "
+                                    "directly for a randomly initialised text encoder)")
+        state = convert_legacy_keys(torch.load(path, map_location='cpu', weights_only=True))
+        own = model.state_dict()
+        if not any(k.startswith('bert.') for k in state):
+            # a bare BertModel checkpoint (keys "embeddings...", "encoder...", "pooler..."): load it into model.bert
+            bare = {k: v for k, v in state.items() if 'bert.' + k in own}
+            if bare:
+                state = {**{'bert.' + k: v for k, v in bare.items()}, **{k: v for k, v in state.items() if k not in bare}}
+        loaded = [k for k in state if k.startswith('bert.') and k in own]
+        if not loaded:
+            raise ValueError(f"TextBert.from_pretrained: {path} holds no parameter of the BERT encoder "
+                             f"(first keys: {list(state)[:5]})")
+        info = model.load_state_dict(state, strict=False)
+        missing_bert = [k for k in info.missing_keys if k.startswith('bert.') and not k.endswith('position_ids')]
+        log = logging.getLogger(__name__)
+        if missing_bert:
+            log.warning("TextBert.from_pretrained: %d BERT parameters keep their random initialisation, e.g. %s",
+                        len(missing_bert), missing_bert[:5])
+        log.info("TextBert.from_pretrained: loaded %d bert.* tensors; missing %s unexpected %s", len(loaded),
+                 info.missing_keys, info.unexpected_keys)
         return model
 
 

@@ -81,6 +81,10 @@ class GraphedMiStep:
         self.graph_fwd: Optional[torch.cuda.CUDAGraph] = None
         self.graph_bwd: Optional[torch.cuda.CUDAGraph] = None
         self.graph_step: Optional[torch.cuda.CUDAGraph] = None
+        # the static inputs, the workspace and the statistics belong to ONE forward at a time: every forward bumps the
+        # generation, and a backward whose forward is no longer the latest one raises instead of silently differentiating
+        # another batch (gradient accumulation over two losses needs two GraphedMiStep objects, or the eager path)
+        self.generation = 0
         if capture:
             self._capture()
 
@@ -127,22 +131,24 @@ class GraphedMiStep:
                 self._bwd()
         torch.cuda.current_stream(self.device).wait_stream(side)
         torch.cuda.synchronize(self.device)
+        # thread_local: another thread's allocator traffic (a DataLoader's pin-memory thread) must not invalidate a capture
         self.graph_fwd = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph_fwd):
+        with torch.cuda.graph(self.graph_fwd, capture_error_mode="thread_local"):
             self._fwd()
         self.graph_bwd = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph_bwd, pool=self.graph_fwd.pool()):
+        with torch.cuda.graph(self.graph_bwd, pool=self.graph_fwd.pool(), capture_error_mode="thread_local"):
             self._bwd()
         # forward + backward as ONE graph for step(): a replay costs ~10 us of fixed overhead, more than the launches of a
         # short backward
         self.graph_step = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph_step, pool=self.graph_fwd.pool()):
+        with torch.cuda.graph(self.graph_step, pool=self.graph_fwd.pool(), capture_error_mode="thread_local"):
             self._fwd()
             self._bwd()
 
     # ------------------------------------------------------------------------------------------ replay
     def forward(self) -> torch.Tensor:
         """Loss of the static inputs (shape [1]; a view of the step's own buffer)."""
+        self.generation += 1
         if self.graph_fwd is not None:
             self.graph_fwd.replay()
         else:
@@ -158,6 +164,7 @@ class GraphedMiStep:
 
     def step(self) -> torch.Tensor:
         """Forward + backward of the static inputs with grad_out as it stands (1 unless changed): one graph replay."""
+        self.generation += 1
         if self.graph_step is not None:
             self.graph_step.replay()
         else:
@@ -167,6 +174,7 @@ class GraphedMiStep:
 
     def step_eager(self) -> torch.Tensor:
         """The same C-ABI calls issued one by one (no replay overhead; needs a host that keeps ahead of ~10 us kernels)."""
+        self.generation += 1
         self._fwd()
         self._bwd()
         return self.loss_buf
@@ -194,11 +202,18 @@ class _GraphedFn(torch.autograd.Function):
         step.y.copy_(y)
         step.forward()
         ctx.step = step
+        ctx.generation = step.generation
         return step.loss_buf.clone()
 
     @staticmethod
     def backward(ctx, grad_loss):
         step = ctx.step
+        if ctx.generation != step.generation:
+            raise RuntimeError(
+                "GraphedMiStep: this loss's forward is no longer the step's latest one (another loss() / forward() / step() "
+                "ran on the same GraphedMiStep before this backward): its static inputs, workspace and statistics now "
+                "belong to the later batch.  Call backward() before the next forward, or use one GraphedMiStep per loss "
+                "that is alive at the same time (or mi_critics.fused_mi_bound, which keeps per-call state).")
         step.grad_out.copy_(grad_loss.reshape(-1)[:1])
         step.backward()
         # clones: autograd may keep (or accumulate into) what it is handed, and the buffers are rewritten next step

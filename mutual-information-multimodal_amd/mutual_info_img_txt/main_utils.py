@@ -83,6 +83,11 @@ def pair_index(study_id: Sequence, device):
     return pair_i[:n], pair_j[:n]
 
 
+def _is_token_features(source) -> bool:
+    """The reference's ``text_token_features``: a list of objects with ``report_id`` / ``input_ids`` / ... fields."""
+    return isinstance(source, (list, tuple)) and bool(source) and hasattr(source[0], "report_id")
+
+
 class MultiModalManager:
     """The reference's MultiModalManager (main_utils.py:53-268) around the MI355X critic path.
 
@@ -130,6 +135,7 @@ class MultiModalManager:
         self.d_img, self.d_txt = d_img, d_txt
         self.training_loss = []
         self._graphed = None
+        self._default_set = False
         self.logger = logging.getLogger(__name__)
 
     def create_mi_pairs(self, embedding_img, embedding_txt, study_id: list, device=None):
@@ -168,6 +174,25 @@ class MultiModalManager:
         return critic(mi_output, len(study_id), embedding_img.device)
 
     # ------------------------------------------------------------------------------------------ batches
+    def _build_loader(self, text_token_features, args):
+        """Dataset + shuffling ``drop_last`` DataLoader of the reference (main_utils.py:123-129), built once per manager:
+        the schedule length ``num_train_epochs * len(data_loader)`` (main_utils.py:168) needs it before the optimisers."""
+        loader = getattr(self, "_loader", None)
+        if loader is None:
+            from .model_utils import build_training_imagereportset
+            dataset = build_training_imagereportset(text_token_features=text_token_features, img_dir=args.image_dir,
+                                                    img_size=getattr(args, "img_size", 256),
+                                                    dataset_metadata=args.dataset_metadata,
+                                                    image_loader=getattr(args, "image_loader", None))
+            # pinned host batches as the reference (main_utils.py:127-129); GraphedMiStep captures with
+            # capture_error_mode="thread_local", so the loader's pin-memory thread cannot invalidate a capture
+            loader = torch.utils.data.DataLoader(dataset, batch_size=args.batch_size, shuffle=True,
+                                                 num_workers=getattr(args, "data_loader_workers", 0),
+                                                 pin_memory=torch.cuda.is_available(), drop_last=True)
+            print(f'Total number of training image-report pairs: {len(dataset)}')
+            self._loader = loader
+        return loader
+
     def _batches(self, source, device, args):
         """One epoch of batches ``(img, txt, study_id)`` or ``(img, txt_ids, txt_masks, txt_segments, study_id, img_id)``.
 
@@ -179,20 +204,17 @@ class MultiModalManager:
             for step in range(int(args.steps_per_epoch)):
                 yield source(step)
             return
-        if isinstance(source, (list, tuple)) and source and hasattr(source[0], "report_id"):
-            loader = getattr(self, "_loader", None)
-            if loader is None:
-                from .model_utils import build_training_imagereportset
-                dataset = build_training_imagereportset(text_token_features=source, img_dir=args.image_dir,
-                                                        img_size=getattr(args, "img_size", 256),
-                                                        dataset_metadata=args.dataset_metadata)
-                loader = torch.utils.data.DataLoader(dataset, batch_size=args.batch_size, shuffle=True,
-                                                     num_workers=getattr(args, "data_loader_workers", 0),
-                                                     pin_memory=True, drop_last=True)
-                print(f'Total number of training image-report pairs: {len(dataset)}')
-                self._loader = loader
-            source = loader
+        if _is_token_features(source):
+            source = self._build_loader(source, args)
+        dataset = getattr(source, "dataset", None)
         for batch in source:
+            if len(batch) == 6 and not self._default_set and hasattr(dataset, "set_default"):
+                # the reference hands sample 0 of the first batch to the dataset as the substitute for unreadable rows
+                # (main_utils.py:195-199); host tensors, before anything moves to the device
+                img, txt_ids, txt_masks, txt_segments, study_id, _ = batch
+                dataset.set_default(img[0].clone().detach(), txt_ids[0].clone().detach(), txt_masks[0].clone().detach(),
+                                    txt_segments[0].clone().detach(), study_id[0])
+                self._default_set = True
             yield batch
 
     def _embed(self, batch, device):
@@ -233,11 +255,16 @@ class MultiModalManager:
             self.model = self.model.to(device)
         mi_optimizer = torch.optim.Adam(self.mi_discriminator.parameters(), lr=args.init_lr)  # main_utils.py:153
         img_optimizer = txt_optimizer = scheduler = None
-        steps_per_epoch = int(getattr(args, "steps_per_epoch", 0) or 0)
-        if not callable(text_token_features) and hasattr(text_token_features, "__len__") and \
-                not (isinstance(text_token_features, (list, tuple)) and text_token_features
-                     and hasattr(text_token_features[0], "report_id")):
+        # schedule length = num_train_epochs * len(data_loader) (reference main_utils.py:168): the loader exists before the
+        # optimisers, as at main_utils.py:123-129
+        if _is_token_features(text_token_features):
+            text_token_features = self._build_loader(text_token_features, args)
+        if callable(text_token_features):
+            steps_per_epoch = int(getattr(args, "steps_per_epoch", 0) or 0)
+        elif hasattr(text_token_features, "__len__"):
             steps_per_epoch = len(text_token_features)
+        else:
+            steps_per_epoch = int(getattr(args, "steps_per_epoch", 0) or 0)
         if self.image_model is not None:
             self.image_model = self.image_model.to(device).train()
             img_params = list(self.image_model.parameters())
@@ -253,6 +280,7 @@ class MultiModalManager:
             txt_optimizer = AdamW(grouped, lr=getattr(args, "txt_lr", 2e-5), correct_bias=False)
             num_train_steps = int(args.num_train_epochs * max(steps_per_epoch, 1))
             scheduler = WarmupLinearSchedule(txt_optimizer, warmup_steps=0.1 * num_train_steps, t_total=num_train_steps)
+        self.scheduler = scheduler
         precision = getattr(args, "precision", "f32")
         use_graph = bool(getattr(args, "graph", True))
         save_dir = getattr(args, "save_directory", None)
@@ -286,6 +314,7 @@ class MultiModalManager:
             logger.info(f"  Epoch {epoch+1} loss = {epoch_loss:.5f}")
             logger.info(f"  Epoch {epoch+1} took {interval:.3f} s")
             if save_dir:
+                os.makedirs(save_dir, exist_ok=True)
                 if self.model is not None:  # main_utils.py:242-245 and the log lines :253-255
                     image_model_file_path = self.model.save_image_model(save_dir)
                     text_model_file_path = self.model.save_text_model(save_dir)
@@ -303,12 +332,22 @@ class MultiModalManager:
 
     def save_training_state(self, save_directory, epoch, mi_optimizer, img_optimizer=None, txt_optimizer=None,
                             scheduler=None):
+        """Critic, optimiser moments, schedule position and finished-epoch count.  Encoder WEIGHTS: the joint
+        ``ImageReportModel`` already writes ``pytorch_model_epoch{n}.bin`` every epoch (projection heads included,
+        main_utils.py:244 of the reference) and that file is what a resume reloads; encoders handed in as plain modules
+        (no joint model) have no file of their own, so their state dicts go into this one."""
         os.makedirs(save_directory, exist_ok=True)
         state = {"epoch": int(epoch), "critic_kind": self.critic_kind, "training_loss": list(self.training_loss),
                  "mi_discriminator": self.mi_discriminator.state_dict(), "mi_optimizer": mi_optimizer.state_dict(),
                  "img_optimizer": None if img_optimizer is None else img_optimizer.state_dict(),
                  "txt_optimizer": None if txt_optimizer is None else txt_optimizer.state_dict(),
-                 "scheduler": None if scheduler is None else {"last_epoch": scheduler.last_epoch}}
+                 "scheduler": None if scheduler is None else {"last_epoch": scheduler.last_epoch},
+                 "image_model": None, "text_model": None}
+        if self.model is None:
+            if self.image_model is not None:
+                state["image_model"] = self.image_model.state_dict()
+            if self.text_model is not None:
+                state["text_model"] = self.text_model.state_dict()
         path = os.path.join(save_directory, self.CRITIC_STATE_FILE)
         torch.save(state, path)
         return path
@@ -316,10 +355,27 @@ class MultiModalManager:
     def load_training_state(self, path, mi_optimizer, img_optimizer=None, txt_optimizer=None, scheduler=None,
                             device=None) -> int:
         """Restore what ``save_training_state`` wrote (tensors, numbers, lists and dicts only: loaded with
-        ``weights_only=True``).  Returns the number of finished epochs."""
+        ``weights_only=True``) AND the encoder weights of the same epoch -- optimiser moments and a late-schedule
+        learning rate paired with freshly initialised encoders would not be a resumed run.  Raises when encoders are
+        attached and their weights of that epoch cannot be found.  Returns the number of finished epochs."""
         if os.path.isdir(path):
             path = os.path.join(path, self.CRITIC_STATE_FILE)
         state = torch.load(path, map_location=device or 'cpu', weights_only=True)
+        epoch = int(state["epoch"])
+        if self.model is not None:
+            from .encoders import JOINT_MODEL_EPOCH_FILE
+            joint = os.path.join(os.path.dirname(path), JOINT_MODEL_EPOCH_FILE.format(epoch))
+            if not os.path.isfile(joint):
+                raise FileNotFoundError(f"resume: encoders are attached but {joint} (the joint checkpoint of epoch {epoch}) "
+                                        "is missing; refusing to pair restored optimiser state with other encoder weights")
+            self.model.load_state_dict(torch.load(joint, map_location=device or 'cpu', weights_only=True))
+        else:
+            for name, module in (("image_model", self.image_model), ("text_model", self.text_model)):
+                if module is None:
+                    continue
+                if state.get(name) is None:
+                    raise FileNotFoundError(f"resume: {name} is attached but {path} holds no weights for it")
+                module.load_state_dict(state[name])
         self.mi_discriminator.load_state_dict(state["mi_discriminator"])
         mi_optimizer.load_state_dict(state["mi_optimizer"])
         if img_optimizer is not None and state.get("img_optimizer") is not None:
@@ -327,9 +383,13 @@ class MultiModalManager:
         if txt_optimizer is not None and state.get("txt_optimizer") is not None:
             txt_optimizer.load_state_dict(state["txt_optimizer"])
         if scheduler is not None and state.get("scheduler") is not None:
+            # LambdaLR.step() sets last_epoch + 1 and the lr from it: set both, so the first resumed step runs at the
+            # learning rate the uninterrupted run would have used
             scheduler.last_epoch = int(state["scheduler"]["last_epoch"])
+            for group, base_lr, fn in zip(scheduler.optimizer.param_groups, scheduler.base_lrs, scheduler.lr_lambdas):
+                group["lr"] = base_lr * fn(scheduler.last_epoch)
         self.training_loss = list(state.get("training_loss", []))
-        return int(state["epoch"])
+        return epoch
 
 
 def _plot_losses(training_loss, path):

@@ -80,7 +80,9 @@ class CXRImageReportDataset(torch.utils.data.Dataset):
                 if img is not None:
                     if self.transform is not None:
                         img = self.transform(img)
-                    img = np.expand_dims(np.asarray(img, dtype=np.float32), axis=0)
+                    # a tensor, like the default sample taken from a collated batch: default_collate cannot stack a
+                    # batch that mixes arrays and tensors
+                    img = torch.from_numpy(np.ascontiguousarray(np.expand_dims(np.asarray(img, dtype=np.float32), axis=0)))
             except Exception as e:  # an unreadable image falls back to the default one
                 self.logger.error(f"Exception loading image for study_id={study_id}, img_id={img_id}: {e!r}")
                 img = None
