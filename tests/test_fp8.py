@@ -6,6 +6,7 @@ the bf16 roundings of G and dT; what is left is fp32 accumulation order, the nat
 T that sits on an e4m3 rounding boundary and comes out one step apart under the fp32- and the fp64-computed scale).
 GPU tests need an MI355X: python -m pytest tests -m gpu"""
 import math
+import os
 
 import numpy as np
 import pytest
@@ -43,7 +44,10 @@ def _dup_ids(b):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("b,dx,dy,est,dup", [(64, 128, 128, "dv", False), (256, 256, 256, "infonce", True),
-                                            (200, 80, 48, "dv", True), (1024, 1024, 1024, "infonce", True)])
+                                            (200, 80, 48, "dv", True), (1024, 1024, 1024, "infonce", True),
+                                            # BASELINE configs[4] at its own size on one GPU (B=8192, d=1024), and half of it
+                                            (4096, 1024, 1024, "infonce", True), (8192, 1024, 1024, "infonce", False),
+                                            (8192, 1024, 1024, "infonce", True)])
 def test_fp8_bilinear_vs_quantised_oracle(dev, b, dx, dy, est, dup):
     from mutual_info_img_txt import _hip, mi_critics
     from mutual_info_img_txt.model import BilinearCritic
@@ -60,6 +64,7 @@ def test_fp8_bilinear_vs_quantised_oracle(dev, b, dx, dy, est, dup):
     loss, scores = mi_critics.fused_mi_bound(xl, yl, sid, critic, est, precision="fp8", return_scores=True)
     loss.sum().backward()
     torch.cuda.synchronize()
+    torch.set_num_threads(min(16, len(os.sched_getaffinity(0))))
     o = orc.bilinear_step_fp8(x, y, w, sid, est)
     sc = max(float(o["scores"].abs().max()), 1.0)
     serr = float((scores.cpu().double() - o["scores"]).abs().max())
