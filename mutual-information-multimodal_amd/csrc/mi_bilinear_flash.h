@@ -159,6 +159,42 @@ __device__ __forceinline__ float fl_max3(float a, float b, float c) {
   return d;
 }
 
+// ---- softmax micro-ops: ONE volatile asm statement each, so that each stays in the MFMA gap it is written in (volatile
+// statements keep their order; hipcc sinks and clumps plain C++ arithmetic, see the kernel).  Hazards the assembler does
+// not pad: an exponential's result needs one wait state before a VALU reads it (callers never put the consumer next to
+// it); a DPP source needs two wait states behind the VALU that wrote it (NOP = true adds them).
+__device__ __forceinline__ void fl_v_exp(float& x) { asm volatile("v_exp_f32 %0, %0" : "+v"(x)); }
+__device__ __forceinline__ void fl_v_add(float& acc, const float& p) { asm volatile("v_add_f32 %0, %0, %1" : "+v"(acc) : "v"(p)); }
+__device__ __forceinline__ unsigned fl_v_cvt_pk(const float& lo, const float& hi) {
+  unsigned d;
+  asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(d) : "v"(lo), "v"(hi));
+  return d;
+}
+// x = s * log2(e) + off
+__device__ __forceinline__ void fl_v_prescale(float& x, const float& s, const float& off) {
+  asm volatile("v_fmamk_f32 %0, %1, 0x3fb8aa3b, %2" : "=v"(x) : "v"(s), "v"(off));
+}
+__device__ __forceinline__ void fl_v_max(float& d, const float& a, const float& b) {
+  asm volatile("v_max_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ void fl_v_max3(float& d, const float& a, const float& b) {
+  asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(d) : "v"(a), "v"(b));
+}
+// step STEP of the wave maximum (the six DPP controls of wave_max_uniform): afterwards lane 63 holds the maximum
+template <int STEP, bool NOP>
+__device__ __forceinline__ void fl_dpp_max(float& v) {
+#define MI_FL_DPP(ctrl)                                                                            \
+  if constexpr (NOP) asm volatile("s_nop 1\n\tv_max_f32_dpp %0, %0, %0 " ctrl : "+v"(v));          \
+  else asm volatile("v_max_f32_dpp %0, %0, %0 " ctrl : "+v"(v))
+  if constexpr (STEP == 0) { MI_FL_DPP("quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf"); }
+  else if constexpr (STEP == 1) { MI_FL_DPP("quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf"); }
+  else if constexpr (STEP == 2) { MI_FL_DPP("row_half_mirror row_mask:0xf bank_mask:0xf"); }
+  else if constexpr (STEP == 3) { MI_FL_DPP("row_mirror row_mask:0xf bank_mask:0xf"); }
+  else if constexpr (STEP == 4) { MI_FL_DPP("row_bcast:15 row_mask:0xa bank_mask:0xf"); }
+  else { MI_FL_DPP("row_bcast:31 row_mask:0xc bank_mask:0xf"); }
+#undef MI_FL_DPP
+}
+
 template <int N>
 __device__ __forceinline__ void fl_wait_vmcnt_barrier() {
   asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
@@ -252,10 +288,9 @@ __device__ __forceinline__ void fl_ring_read_v(bf16x8& f, int addr_lo, int addr_
 // s (+)= A x B with A = ring fragment (streamed rows), B = stationary fragment (either register file).
 // NOTE on the accumulator: hipcc may copy an asm operand between two statements.  With a plain C++ "previous = next" at
 // the end of the pipelined loop it renamed the score accumulator in the MIDDLE of the chain to coalesce that copy
-// (v_mov of an MFMA result still in the matrix pipe: wrong scores, no fault).  The copy is therefore made by
-// fl_copy_scores (asm: nothing to coalesce, and it sits behind the whole output product), and
-// tools/diag/audit_flash_isa.py checks the compiled kernel for any compiler-issued instruction that touches the
-// destination of an MFMA still in flight.
+// (v_mov of an MFMA result still in the matrix pipe: wrong scores, no fault).  There is no such copy any more (the
+// softmax head writes the prescaled scores into registers of its own), and tools/diag/audit_flash_isa.py checks the
+// compiled kernel for any compiler-issued instruction that touches the destination of an MFMA still in flight.
 // WAIT >= 0: `s_waitcnt lgkmcnt(WAIT)` first (its own volatile statement: volatile asms keep their order); WAIT < 0: none.
 // Only every second MFMA waits, for its own fragment and the next one's: a wait is an issue slot next to the MFMAs
 // whether or not it has anything to wait for (71 of them per streamed tile before).
@@ -263,6 +298,14 @@ template <int WAIT>
 __device__ __forceinline__ void fl_wait_lgkm() {
   if constexpr (WAIT >= 0) asm volatile("s_waitcnt lgkmcnt(%c0)" ::"i"(WAIT) : "memory");
 }
+// The ACCUMULATING form names the accumulator as an input only and writes it behind hipcc's back.  Declared "+v", hipcc
+// pads one wait state (s_nop 0) between any two consecutive asm statements of which the second reads what the first
+// wrote (asm statements in between do not count for it): an issue slot per MFMA of the chain, 4 of the ~24 cycles a gap
+// can hide.  What makes the lie safe: (1) nothing but these statements reads the accumulator while a chain is open --
+// the first reader of the finished chain sits behind `asm volatile("" : "+v"(s_next))`, which hands hipcc a NEW value in
+// the same registers; (2) a copy hipcc might slip between two statements would change the register the next statement
+// names: tools/diag/audit_flash_isa.py checks that all D / 16 MFMAs of a chain accumulate the same registers and that no
+// other instruction touches them meanwhile.
 template <bool B_IN_ACC, bool FIRST, int WAIT>
 __device__ __forceinline__ void fl_mfma_s(f32x16& acc, const bf16x8& a, const bf16x8& b) {
   fl_wait_lgkm<WAIT>();
@@ -273,14 +316,15 @@ __device__ __forceinline__ void fl_mfma_s(f32x16& acc, const bf16x8& a, const bf
       asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=v"(acc) : "v"(a), "v"(b));
   } else {
     if constexpr (B_IN_ACC)
-      asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "a"(b));
+      asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : : "v"(acc), "v"(a), "a"(b));
     else
-      asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+      asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : : "v"(acc), "v"(a), "v"(b));
   }
 }
 // o += P x V with P (A operand) in VGPRs, V = ring fragment
-template <bool ACC_IN_ACC, bool NOP, int WAIT>
-__device__ __forceinline__ void fl_mfma_o(f32x16& acc, const bf16x8& a, const bf16x8& b) {
+template <bool ACC_IN_ACC, bool NOP, int WAIT, class AT>
+__device__ __forceinline__ void fl_mfma_o(f32x16& acc, const AT& a, const bf16x8& b) {
+  static_assert(sizeof(AT) == 16, "a 32x32x16 bf16 operand is four registers");
   fl_wait_lgkm<WAIT>();
   if constexpr (NOP) {
     if constexpr (ACC_IN_ACC)
@@ -318,15 +362,6 @@ __device__ __forceinline__ void fl_scale_tile(f32x16& t, float f) {
     } else {
       t[r] *= f;
     }
-  }
-}
-__device__ __forceinline__ void fl_copy_scores(f32x16& dst, f32x16& src) {
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    float d;
-    const float e = src[r];
-    asm volatile("v_mov_b32 %0, %1" : "=v"(d) : "v"(e));
-    dst[r] = d;
   }
 }
 template <bool IN_ACC>
@@ -532,93 +567,141 @@ __global__ __launch_bounds__(256, 1) void bilinear_flash_kernel(FlashArgs args) 
   fl_static_for<0, C::NK>([&](auto KK) __attribute__((always_inline)) { fl_pin<(decltype(KK)::value < C::QA)>(qf[decltype(KK)::value]); });
   if constexpr (GRAD) fl_static_for<0, C::NT>([&](auto CT) __attribute__((always_inline)) { fl_pin_o<(decltype(CT)::value < C::OA)>(o[decltype(CT)::value]); });
 
-  constexpr bool kHeadInPv = GRAD && 2 * C::NT >= 32;  // enough output-product gaps to take the softmax head (D = 512)
   bf16x8 ring[kFlRing];
-  bf16x8 pf[2];
-  f32x16 s_prev, s_next;  // scores of the tile whose exponentials are due / of the tile being multiplied
+  u32x4 pfw[2];    // P of the tile being multiplied, packed bf16 pairs: the A operand of the output product
+  f32x16 s_next;   // scores of the newest tile (the score product's accumulator)
+  float xs[16];    // the pending tile: prescaled scores (x - m_ref) log2(e), then -- in place -- their exponentials
+  float tA = MI_NEG_INF, tB = MI_NEG_INF, off = 0.0f;
+  float tM = MI_NEG_INF;   // masked tiles: lane maximum over the unmasked entries,
+  unsigned mbits = 0u;     // ... bit r set = accumulator element r is masked,
+  bool rare = false;       // ... and the (wave-uniform) flag that the newest tile is such a tile
+  float f_pend = 1.0f;  // a raise of the reference point decided beside the output product is APPLIED to the sums at the
+  bool pend = false;    // next iteration's start, when every product of the old reference point has been issued
 
-  // ---- softmax of the finished tile `s_prev` (tile index tp), cut into NSL slices that are placed one per MFMA gap of the
-  // next tile's score product.  Slice 0 holds the (rare) general mask; every other slice is a handful of VALU ops.
-  float tmax = MI_NEG_INF, off = 0.0f;
-  constexpr int NSL = 32;
-  auto sm_slice = [&](auto SI, int tp, f32x16& s_prev) __attribute__((always_inline)) {  // (shadows the tile's name)
-    constexpr int si = decltype(SI)::value;
+  // ---- softmax of a tile as two lists of micro-ops, each ONE volatile asm statement placed in a chosen MFMA gap.
+  // Written as plain C++ in "slices" hipcc undid the placement (ISA of round 2: the sixteen lsum additions sunk into one
+  // dependent chain behind the last MFMA, eight of the exponentials and their packing in a single gap, the wave maximum as
+  // thirty instructions in another; ~690 cycles per tile that no MFMA hid).  Volatile statements keep their order
+  // relative to the MFMAs and reads (which are volatile statements too).
+  //  * HEAD of tile tn (scores in s_next), beside the OUTPUT product of tile tn - 1: mask / positives (rare, C++), lane
+  //    maxima, wave maximum (6 DPP steps), reference-point decision, x = s * log2(e) - m_ref * log2(e) into xs[].
+  //    Writing xs[] here replaces the sixteen register copies "previous = next" of round 2.
+  //  * TAIL of tile tp (xs[]), beside the SCORE product of tile tp + 1: p = exp2(x) in place, lsum += p one slot later
+  //    (no dependent back-to-back pair: an exponential's consumer needs a wait state), cvt_pk pairs two slots later.
+  constexpr int kTailSlots = 17, kHeadSlots = 17;
+  auto tail_slot = [&](auto S_) __attribute__((always_inline)) {
+    constexpr int sl = decltype(S_)::value;
 #ifdef MI_STAMPS
     if (args.diag & 2) return;
 #endif
-    if constexpr (si == 0) {
-      if (__builtin_amdgcn_readfirstlane((int)((dupmask >> tp) & 1ull))) {
+    if constexpr (sl < 16) fl_v_exp(xs[sl]);
+    if constexpr (sl >= 1 && sl <= 16) fl_v_add(lsum, xs[sl - 1]);
+    if constexpr (GRAD && sl >= 2 && sl <= 16 && sl % 2 == 0) {
+      constexpr int k = sl / 2 - 1;  // dword k & 3 of fragment k >> 2 = (bf16(p[2k]), bf16(p[2k + 1]))
+      pfw[k >> 2][k & 3] = fl_v_cvt_pk(xs[2 * k], xs[2 * k + 1]);
+    }
+  };
+  // NOPS: the ops run back to back (no MFMA and reads between them): a DPP step then needs two wait states behind the
+  // VALU write of its source
+  auto head_slot = [&](auto V_, auto NOPS_, int tn) __attribute__((always_inline)) {
+    constexpr int v = decltype(V_)::value;
+    constexpr bool NOPS = decltype(NOPS_)::value;
+#ifdef MI_STAMPS
+    if (args.diag & 2) return;
+#endif
+    if constexpr (v == 0) {
+      asm volatile("" : "+v"(s_next));  // nothing below reads the scores earlier than this point of the stream
+      // Masked tiles (rare: the diagonal, duplicated study ids) never WRITE the score registers: a C++ write to the MFMA's
+      // accumulator tuple made hipcc build the masked tile in new registers and copy all sixteen in the unmasked path.
+      // Instead the rare path takes its own lane maximum over the unmasked entries (tM replaces the lanes' maxima in slot
+      // 4) and remembers the masked entries as bits; their prescaled scores are set to -inf behind the last slot.
+      if (__builtin_amdgcn_readfirstlane((int)((dupmask >> tn) & 1ull))) {
         MI_FL_STAMP(5);
         // some pair of this tile shares a study id (always so on the diagonal): exact 64-bit compares, positives
-        const int64_t* sl = reinterpret_cast<const int64_t*>(smem + C::SID_OFF) + tp * kFlBN + 4 * half;
-        const int d0 = d0_wave - tp * kFlBN;  // streamed row (inside this tile) of stationary row 0's positive
+        const int64_t* sl = reinterpret_cast<const int64_t*>(smem + C::SID_OFF) + tn * kFlBN + 4 * half;
+        const int d0 = d0_wave - tn * kFlBN;  // streamed row (inside this tile) of stationary row 0's positive
         if (__builtin_amdgcn_readfirstlane((int)(d0 > -32 && d0 < 32))) {
           const int want = r32 + d0 - 4 * half;
 #pragma unroll
-          for (int r = 0; r < 16; ++r) pos += (want == (r & 3) + 8 * (r >> 2)) ? s_prev[r] : 0.0f;
+          for (int r = 0; r < 16; ++r) pos += (want == (r & 3) + 8 * (r >> 2)) ? s_next[r] : 0.0f;
         }
         MI_FL_STAMP(7);
+        tM = MI_NEG_INF;
+        mbits = 0u;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const bool neg = sl[(r & 3) + 8 * (r >> 2)] != sid_i;
           cnt += (unsigned)__popcll(__ballot(neg));
-          s_prev[r] = neg ? s_prev[r] : MI_NEG_INF;
+          tM = neg ? fmaxf(tM, s_next[r]) : tM;
+          mbits |= neg ? 0u : (1u << r);
         }
+        rare = true;
         MI_FL_STAMP(6);
-      } else if (__builtin_amdgcn_readfirstlane((int)((diagmask >> tp) & 1ull))) {
+      } else if (__builtin_amdgcn_readfirstlane((int)((diagmask >> tn) & 1ull))) {
         // the tile's main diagonal holds this wave's 32 positives and no other pair is masked: streamed row r32 - 4 half
         // of the lane's column ... i.e. accumulator element (r & 3) + 8 (r >> 2) == r32 - 4 half.  No id loads, a third
         // of the general path's instructions (whose cold instruction fetch alone cost ~5,000 cycles per occurrence).
         const int want = r32 - 4 * half;
+        tM = MI_NEG_INF;
+        mbits = 0u;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const bool p = want == (r & 3) + 8 * (r >> 2);
-          pos += p ? s_prev[r] : 0.0f;
-          s_prev[r] = p ? MI_NEG_INF : s_prev[r];
+          pos += p ? s_next[r] : 0.0f;
+          tM = p ? tM : fmaxf(tM, s_next[r]);
+          mbits |= p ? (1u << r) : 0u;
         }
         cnt += 1024u - 32u;
+        rare = true;
       } else {
         cnt += 1024u;
       }
-      tmax = fl_max3(s_prev[0], s_prev[1], MI_NEG_INF);
-    } else if constexpr (si >= 1 && si <= 7) {
-      tmax = fl_max3(tmax, s_prev[2 * si], s_prev[2 * si + 1]);
-    } else if constexpr (si == 8) {
-      tmax = wave_max_uniform(tmax);
-    } else if constexpr (si == 9) {
+      fl_v_max(tA, s_next[0], s_next[1]);
+      fl_v_max(tB, s_next[2], s_next[3]);
+    } else if constexpr (v >= 1 && v <= 3) {
+      fl_v_max3(tA, s_next[4 * v], s_next[4 * v + 1]);
+      fl_v_max3(tB, s_next[4 * v + 2], s_next[4 * v + 3]);
+    } else if constexpr (v == 4) {
+      fl_v_max(tA, tA, tB);
+      if (rare) tA = tM;
+      fl_dpp_max<0, true>(tA);  // (behind the merge: always two wait states)
+    } else if constexpr (v >= 5 && v <= 9) {
+      fl_dpp_max<v - 4, NOPS>(tA);
+    } else if constexpr (v == 10) {
+      const float tmax = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(tA), 63));  // wave-uniform
       if (tmax > mref + kFlThr || (mref == MI_NEG_INF && tmax > MI_NEG_INF)) {
         if (mref > MI_NEG_INF) {
-          const float f = __builtin_amdgcn_exp2f((mref - tmax) * kLog2e);
-          lsum *= f;
-          if constexpr (GRAD) {
-            fl_mfma_drain_all();
-            fl_static_for<0, C::NT>([&](auto CT) __attribute__((always_inline)) { fl_scale_tile<(decltype(CT)::value < C::OA)>(o[decltype(CT)::value], f); });
-          }
+          f_pend = __builtin_amdgcn_exp2f((mref - tmax) * kLog2e);
+          pend = true;
         }
         mref = tmax;
       }
       off = mref > MI_NEG_INF ? -mref * kLog2e : 0.0f;
-    } else if constexpr (si >= 10 && si <= 25) {
-      constexpr int r = si - 10;
-      s_prev[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s_prev[r], kLog2e, off));  // masked entries: exp2(-inf) = 0
-      lsum += s_prev[r];
-    } else if constexpr (si == 26 || si == 27) {
-      if constexpr (GRAD) {
-        constexpr int ks = si - 26;
+    } else if constexpr (v >= 11 && v <= 14) {
+      constexpr int r = 3 * (v - 11);
+      fl_v_prescale(xs[r], s_next[r], off);
+      fl_v_prescale(xs[r + 1], s_next[r + 1], off);
+      fl_v_prescale(xs[r + 2], s_next[r + 2], off);
+    } else if constexpr (v == 15 || v == 16) {
+      constexpr int r = 12 + 2 * (v - 15);
+      fl_v_prescale(xs[r], s_next[r], off);
+      fl_v_prescale(xs[r + 1], s_next[r + 1], off);
+      if constexpr (v == 16) {
+        if (rare) {  // masked entries: -inf, exp2 gives 0
 #pragma unroll
-        for (int e = 0; e < 8; ++e) pf[ks][e] = (bf16_t)s_prev[8 * ks + e];
+          for (int q = 0; q < 16; ++q) xs[q] = ((mbits >> q) & 1u) ? MI_NEG_INF : xs[q];
+          rare = false;
+        }
       }
     }
   };
 
-  // ---- one loop iteration: [score product of tile tn = tp + 1 (HAS_S)] with the softmax slices of tile tp in its MFMA
-  // gaps, then [output product of tile tp (HAS_V)] with the LDS-DMA pieces of tile tp + 3 in its gaps
-  // HEAD_DONE: slices [0, 9) of tile tp (mask, tile maximum) already ran in the output-product gaps of the previous
-  // iteration (D = 512 with gradients: kHeadInPv) -- only the reference-point decision is left of the head.
-  auto iteration = [&](auto HAS_S_, auto HAS_V_, auto HEAD_DONE_, int tp) __attribute__((always_inline)) {
+  // ---- one loop iteration: [score product of tile tn = tp + 1 (HAS_S)] with the TAIL of tile tp in its MFMA gaps, then
+  // [output product of tile tp (HAS_V)] with, in its gaps, the HEAD of tile tn and the LDS-DMA pieces of tile tp + 3.
+  // Where a product is missing (first / last tile, forward-only kernel) the list it would have carried runs on its own.
+  auto iteration = [&](auto HAS_S_, auto HAS_V_, int tp) __attribute__((always_inline)) {
     constexpr bool HAS_S = decltype(HAS_S_)::value, HAS_V = decltype(HAS_V_)::value && GRAD;
-    constexpr bool DO_SM = decltype(HAS_V_)::value;  // a finished tile is waiting for its exponentials
-    constexpr int H0 = decltype(HEAD_DONE_)::value ? 9 : 0;  // first slice still to run
+    constexpr bool DO_TAIL = decltype(HAS_V_)::value;  // a finished tile is waiting for its exponentials
     constexpr int NS = HAS_S ? C::NK : 0, NV = HAS_V ? 2 * C::NT : 0, NF = NS + NV;
     const int so = ((tp + 1) & (kFlStages - 1)) * C::STAGE + a0_lane;  // row reads of tile tp + 1
     const int vo = (tp & (kFlStages - 1)) * C::STAGE + a1_lane;       // transposed reads of tile tp
@@ -642,33 +725,41 @@ __global__ __launch_bounds__(256, 1) void bilinear_flash_kernel(FlashArgs args) 
       }
     };
     fl_static_for<0, kFlAhead>([&](auto NI) __attribute__((always_inline)) { issue_read(NI); });
-    // The head of the softmax (mask, tile maximum, reference-point decision: slices [0, HEAD)) runs right here, in the
-    // shadow of the first fragment reads' LDS latency; the exponentials and the bf16 packing go one slice per MFMA gap.
-    constexpr int HEAD = 10;
-    if constexpr (DO_SM && HAS_S) {
-      fl_static_for<H0, HEAD>([&](auto SI) __attribute__((always_inline)) { sm_slice(SI, tp, s_prev); });
-      __builtin_amdgcn_sched_barrier(0);
+    // a raise of the reference point decided during the previous output product: every sum still stands at the old point
+    // (this tile's exponentials, taken against the new one, have not been added yet)
+    if (pend) {
+      lsum *= f_pend;
+      if constexpr (GRAD) {
+        fl_mfma_drain_all();
+        fl_static_for<0, C::NT>([&](auto CT) __attribute__((always_inline)) { fl_scale_tile<(decltype(CT)::value < C::OA)>(o[decltype(CT)::value], f_pend); });
+      }
+      pend = false;
     }
-    // score product + the remaining softmax slices
+    __builtin_amdgcn_sched_barrier(0);
+    // score product; the TAIL slots spread over its gaps in order
     fl_static_for<0, NS>([&](auto NI) __attribute__((always_inline)) {
       constexpr int n = decltype(NI)::value;
       fl_mfma_s<(n < C::QA), n == 0, fl_wait_count<NS, NV>(n)>(s_next, ring[n % kFlRing], qf[n]);
       issue_read(std::integral_constant<int, n + kFlAhead>{});
-      if constexpr (DO_SM) {
+      if constexpr (DO_TAIL) {
         constexpr int NSD = NS > 0 ? NS : 1;
-        constexpr int per = (NSL - HEAD + NSD - 1) / NSD;  // slices per gap (1 at D = 512, 2 at 256, 3 at 128)
-        constexpr int lo = HEAD + n * per, hi = (lo + per < NSL ? lo + per : NSL);
-        fl_static_for<(lo < NSL ? lo : NSL), hi>([&](auto SI) __attribute__((always_inline)) { sm_slice(SI, tp, s_prev); });
+        constexpr int per = (kTailSlots + NSD - 1) / NSD;  // 1 at D = 512, 2 at 256, 3 at 128
+        constexpr int lo = n * per, hi = (lo + per < kTailSlots ? lo + per : kTailSlots);
+        fl_static_for<(lo < kTailSlots ? lo : kTailSlots), hi>([&](auto SI) __attribute__((always_inline)) { tail_slot(SI); });
       }
       __builtin_amdgcn_sched_barrier(0);
     });
-    if constexpr (DO_SM && !HAS_S) fl_static_for<H0, NSL>([&](auto SI) __attribute__((always_inline)) { sm_slice(SI, tp, s_prev); });
-    if constexpr (HAS_S && !HAS_V) {
-      fl_score_fence<true>(s_next);  // with an output product behind it the chain is long done
-      // no output-product gaps to put the head of the new tile in: once, right here (the pipeline's first tile)
-      if constexpr (kHeadInPv) fl_static_for<0, 9>([&](auto SI) __attribute__((always_inline)) { sm_slice(SI, tp + 1, s_next); });
+    if constexpr (DO_TAIL && !HAS_S) {
+      fl_static_for<0, kTailSlots>([&](auto SI) __attribute__((always_inline)) { tail_slot(SI); });
+      __builtin_amdgcn_sched_barrier(0);
     }
-    // output product + LDS-DMA issue for tile tp + 3
+    if constexpr (HAS_S && !HAS_V) {
+      // no output product to carry the new tile's HEAD (the pipeline's first tile; the forward-only kernel)
+      fl_score_fence<true>(s_next);
+      fl_static_for<0, kHeadSlots>([&](auto VI) __attribute__((always_inline)) { head_slot(VI, std::true_type{}, tp + 1); });
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // output product + HEAD of the next tile + LDS-DMA issue for tile tp + 3
     if constexpr (HAS_V) {
       constexpr int EVERY = NV / C::PIECES;
       const bool more = tp + 3 < nt;
@@ -680,18 +771,23 @@ __global__ __launch_bounds__(256, 1) void bilinear_flash_kernel(FlashArgs args) 
       const void* sb1 = (const char*)sb0 + 4096;
       const unsigned lb = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(((tp + 3) & (kFlStages - 1)) * C::STAGE) +
                                                          (unsigned)(wave * (C::PIECES * 1024)));
+      // gaps that may carry HEAD slots: from the sixth on (the score chain ended >= 5 MFMAs and their reads earlier: the
+      // matrix pipe's result is readable), and not the ones that carry an LDS-DMA piece
+      constexpr int U0 = 5;
+      constexpr int n_avail = (NV - U0) - (NV / EVERY - U0 / EVERY);  // gaps u >= U0 without a piece (pieces sit at u % EVERY == EVERY - 1)
+      static_assert(n_avail >= 1, "no gap for the softmax head");
       fl_static_for<0, NV>([&](auto UI) __attribute__((always_inline)) {
         constexpr int u = decltype(UI)::value, n = NS + u, ks = u / C::NT, ct = u % C::NT;
-        fl_mfma_o<(ct < C::OA), (u % C::NT == 0), fl_wait_count<NS, NV>(n)>(o[ct], pf[ks], ring[n % kFlRing]);
+        fl_mfma_o<(ct < C::OA), (u % C::NT == 0), fl_wait_count<NS, NV>(n)>(o[ct], pfw[ks], ring[n % kFlRing]);
         issue_read(std::integral_constant<int, n + kFlAhead>{});
-        if constexpr (HAS_S && kHeadInPv) {
-          // the next tile's scores are final (their chain ended >= 5 MFMAs ago): mask and maximum here, in gaps that
-          // carry no LDS-DMA piece, instead of at the head of the next iteration where nothing hides them
-          constexpr int hs = u == 5 ? 0 : u == 6 ? 1 : u == 8 ? 2 : u == 9 ? 3 : u == 10 ? 4 : u == 12 ? 5 : u == 13 ? 6
-                             : u == 14 ? 7 : u == 16 ? 8 : -1;
-          if constexpr (hs >= 0) sm_slice(std::integral_constant<int, hs>{}, tp + 1, s_next);
+        constexpr bool dma_gap = u % EVERY == EVERY - 1;
+        if constexpr (HAS_S && u >= U0 && !dma_gap) {
+          constexpr int k = (u - U0) - (u / EVERY - U0 / EVERY);  // index among the available gaps
+          constexpr int lo = k * kHeadSlots / n_avail, hi = (k + 1) * kHeadSlots / n_avail;
+          constexpr bool nops = kHeadSlots > n_avail;  // several slots share a gap
+          fl_static_for<lo, hi>([&](auto VI) __attribute__((always_inline)) { head_slot(VI, std::integral_constant<bool, nops>{}, tp + 1); });
         }
-        if constexpr (u % EVERY == EVERY - 1) {
+        if constexpr (dma_gap) {
           constexpr int i = u / EVERY;
           if (more) {
 #ifdef MI_STAMPS
@@ -704,8 +800,7 @@ __global__ __launch_bounds__(256, 1) void bilinear_flash_kernel(FlashArgs args) 
         }
         __builtin_amdgcn_sched_barrier(0);
       });
-      if constexpr (HAS_S) fl_score_fence<false>(s_next);  // readers of s_next stay behind the output product
-    } else if constexpr (DO_SM) {
+    } else if constexpr (DO_TAIL) {
       if (tp + 3 < nt) issue_tile(tp + 3);
     }
   };
@@ -713,9 +808,8 @@ __global__ __launch_bounds__(256, 1) void bilinear_flash_kernel(FlashArgs args) 
   using F_ = std::false_type;
 
   if (nt > 0) {
-    // tile 0's scores, nothing to overlap with yet (tp = -1: the "next" tile is tile 0)
-    iteration(T_{}, F_{}, F_{}, -1);
-    fl_copy_scores(s_prev, s_next);
+    // tile 0's scores and HEAD, nothing to overlap with yet (tp = -1: the "next" tile is tile 0)
+    iteration(T_{}, F_{}, -1);
     for (int t = 0; t + 1 < nt; ++t) {
       if (t == nt / 2) MI_FL_STAMP(2);
       // tile t + 1 must have landed (own pieces, then everybody's); every wave is done with tile t - 1, whose stage the
@@ -727,12 +821,11 @@ __global__ __launch_bounds__(256, 1) void bilinear_flash_kernel(FlashArgs args) 
       if (t + 2 < nt) fl_wait_vmcnt_barrier<C::PIECES>();
       else fl_wait_vmcnt_barrier<0>();
       if (t == nt / 2) MI_FL_STAMP(3);
-      iteration(T_{}, T_{}, std::integral_constant<bool, kHeadInPv>{}, t);
-      fl_copy_scores(s_prev, s_next);
+      iteration(T_{}, T_{}, t);
       if (t == nt / 2) MI_FL_STAMP(4);
     }
     MI_FL_STAMP(8);
-    iteration(F_{}, T_{}, std::integral_constant<bool, kHeadInPv>{}, nt - 1);
+    iteration(F_{}, T_{}, nt - 1);
   }
   MI_FL_STAMP(9);
 

@@ -11,7 +11,11 @@ every bilinear_flash_kernel instantiation:
     fewer than WAIT_STATES wait states earlier (one per instruction, N + 1 per `s_nop N`);
   * no scratch (spill) instruction inside a loop;
   * no `s_waitcnt vmcnt(0)` inside a loop (it would drain the LDS-DMA prefetch);
-  * no compiler-generated instruction uses M0 (the loop's LDS-DMA pieces set M0 from asm without saving it).
+  * no compiler-generated instruction uses M0 (the loop's LDS-DMA pieces set M0 from asm without saving it);
+  * every score chain is ONE accumulator: the MFMA that starts a chain (C operand 0) and the D / 16 - 1 MFMAs behind it
+    write and accumulate the same registers.  (The accumulating statements name the accumulator as an INPUT only -- as
+    an output, hipcc pads a wait state between any two consecutive asm statements of a chain -- so nothing but this
+    check would notice a register copy slipped in between two of them.)
 
 Exit status 0 = clean.  Used by tests/test_flash_isa_audit.py (CPU suite) and by hand after kernel edits.
 """
@@ -60,6 +64,9 @@ def audit(name, body):
     seen_mfma = False  # the prologue's id-copy loop legitimately waits for its plain loads
     lines = body.split("\n")
     in_asm = False
+    m = re.search(r"ILi(\d+)E", name)
+    chain_len = int(m.group(1)) // 16 if m else 0
+    chain = None  # [destination registers, MFMAs seen]
     for ln, raw in enumerate(lines, 1):
         if "#ASMSTART" in raw:
             in_asm = True
@@ -90,6 +97,16 @@ def audit(name, body):
                     problems.append(f"{name}:{ln}: MFMA overlaps an in-flight MFMA destination partially: {line}")
             inflight.append([dst, 0])
             seen_mfma = True
+            if len(parts) > 3 and parts[3] == "0":
+                if chain is not None:
+                    problems.append(f"{name}:{ln}: a score chain starts {chain[1]} MFMAs into the previous one")
+                chain = [dst, 1]
+            elif chain is not None:
+                if dst != chain[0] or srcc != chain[0]:
+                    problems.append(f"{name}:{ln}: MFMA {chain[1] + 1} of a score chain does not accumulate the chain's registers: {line}")
+                chain[1] += 1
+            if chain is not None and chain[1] == chain_len:
+                chain = None
         else:
             touched = regs_of(operands)
             for regs, age in inflight:
