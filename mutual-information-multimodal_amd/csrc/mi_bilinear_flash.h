@@ -51,6 +51,15 @@ namespace mi {
 #define MI_FL_STAMP(slot) do {} while (0)
 #endif
 
+// Timing experiments with WRONG results (diagnostic builds only: make STAMPS=1 DIAG=<bits>):
+// bit 0 no LDS-DMA in the loop, bit 1 no softmax, bit 2 no workgroup barrier in the loop, bit 3 no fragment reads,
+// bit 4 no counted LDS waits; bits 5..9: no exponentials / no sum additions / no bf16 packing / no softmax head up
+// to the reference-point decision / no prescaling.  Compile-time: a run-time test per MFMA gap costs more than what it
+// switches off (a scalar branch beside the MFMAs is several issue slots).
+#ifndef MI_FL_DIAG
+#define MI_FL_DIAG 0
+#endif
+constexpr int kFlDiag = MI_FL_DIAG;
 constexpr int kFlRows = 128;     // stationary rows per workgroup
 constexpr int kFlBN = 32;        // streamed rows per tile
 constexpr int kFlStages = 4;     // LDS stages (three tiles in flight)
@@ -77,8 +86,7 @@ struct FlashArgs {
   int n_problems;
   int n_combo;  // (problem, split) pairs, padded to a multiple of 8
   int xcd_rows; // 1: (problem, row block) units pinned to XCDs; 0: (problem, split) pairs pinned to XCDs
-  int diag;     // diagnostic (MI_STAMPS) builds only, timing experiments with WRONG results: bit 0 no LDS-DMA in the loop,
-                // bit 1 no softmax slices, bit 2 no workgroup barrier in the loop (MI_FLASH_DIAG in the environment)
+  int diag;     // unused (the timing experiments are compile-time switches: MI_FL_DIAG)
   int slab_f16; // 1: scaled fp16 slabs (see FlashProblem::slab)
   int no_index_mask;  // A/B switch MI_FLASH_NO_INDEX_MASK: diagonal-only tiles take the exact id compares as well
 };
@@ -142,13 +150,19 @@ __device__ __forceinline__ void fl_dma16(unsigned voff, const void* sbase, unsig
 // M0 is NOT saved: hipcc emits no M0 use of its own in this kernel, which tools/diag/audit_flash_isa.py verifies.
 // The lane offset of piece i is vlane_w ^ XORC (a compile-time constant per piece: the swizzle term is XOR-linear in the
 // piece number), formed in the statement: eight precomputed offsets cost eight registers this kernel does not have.
-template <int LOFF, int GOFF, int XORC>
-__device__ __forceinline__ void fl_dma16_at(unsigned vlane_w, const void* sbase, unsigned lds_base) {
+template <int LOFF>
+__device__ __forceinline__ void fl_dma_set_m0(unsigned lds_base) {
+  asm volatile("s_add_u32 m0, %0, %1" : : "s"(lds_base), "n"(LOFF) : "scc");
+}
+// ... and M0 is written only where LOFF changes (twice per tile, two gaps ahead of the piece that needs it: no wait state
+// to pad), so that a piece is TWO instructions beside the MFMAs.
+template <int GOFF, int XORC>
+__device__ __forceinline__ void fl_dma16_at(unsigned vlane_w, const void* sbase) {
   unsigned voff;
-  asm volatile("v_xor_b32 %0, %5, %1\n\ts_add_u32 m0, %3, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %2 offset:%6"
+  asm volatile("v_xor_b32 %0, %3, %1\n\tglobal_load_lds_dwordx4 %0, %2 offset:%4"
                : "=&v"(voff)
-               : "v"(vlane_w), "s"(sbase), "s"(lds_base), "n"(LOFF), "n"(XORC), "n"(GOFF)
-               : "memory", "scc");
+               : "v"(vlane_w), "s"(sbase), "n"(XORC), "n"(GOFF)
+               : "memory");
 }
 
 // max of three without the canonicalising v_max(x, x) hipcc puts in front of fmaxf on MFMA outputs (NaNs propagate to
@@ -163,8 +177,13 @@ __device__ __forceinline__ float fl_max3(float a, float b, float c) {
 // statements keep their order; hipcc sinks and clumps plain C++ arithmetic, see the kernel).  Hazards the assembler does
 // not pad: an exponential's result needs one wait state before a VALU reads it (callers never put the consumer next to
 // it); a DPP source needs two wait states behind the VALU that wrote it (NOP = true adds them).
-__device__ __forceinline__ void fl_v_exp(float& x) { asm volatile("v_exp_f32 %0, %0" : "+v"(x)); }
-__device__ __forceinline__ void fl_v_add(float& acc, const float& p) { asm volatile("v_add_f32 %0, %0, %1" : "+v"(acc) : "v"(p)); }
+// The exponential and the addition name what they overwrite as an INPUT only (as fl_mfma_s does, and for the same
+// reason: hipcc pads a wait state in front of an asm statement that reads what the asm statement before it wrote).  The
+// values stay opaque to hipcc: the prescaled scores are asm outputs, and fl_v_opaque(lsum) hands it a new value of the
+// running sum once per iteration and before the sum is read.
+__device__ __forceinline__ void fl_v_exp(const float& x) { asm volatile("v_exp_f32 %0, %0" : : "v"(x)); }
+__device__ __forceinline__ void fl_v_add(const float& acc, const float& p) { asm volatile("v_add_f32 %0, %0, %1" : : "v"(acc), "v"(p)); }
+__device__ __forceinline__ void fl_v_opaque(float& x) { asm volatile("" : "+v"(x)); }
 __device__ __forceinline__ unsigned fl_v_cvt_pk(const float& lo, const float& hi) {
   unsigned d;
   asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(d) : "v"(lo), "v"(hi));
@@ -180,12 +199,14 @@ __device__ __forceinline__ void fl_v_max(float& d, const float& a, const float& 
 __device__ __forceinline__ void fl_v_max3(float& d, const float& a, const float& b) {
   asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(d) : "v"(a), "v"(b));
 }
-// step STEP of the wave maximum (the six DPP controls of wave_max_uniform): afterwards lane 63 holds the maximum
+// step STEP of the wave maximum (the six DPP controls of wave_max_uniform): afterwards lane 63 holds the maximum.  The
+// register is named as an input only (see fl_v_exp); the value is written by an asm statement before the first step and
+// read by one (v_readlane in the decision statement) after the last.
 template <int STEP, bool NOP>
-__device__ __forceinline__ void fl_dpp_max(float& v) {
+__device__ __forceinline__ void fl_dpp_max(const float& v) {
 #define MI_FL_DPP(ctrl)                                                                            \
-  if constexpr (NOP) asm volatile("s_nop 1\n\tv_max_f32_dpp %0, %0, %0 " ctrl : "+v"(v));          \
-  else asm volatile("v_max_f32_dpp %0, %0, %0 " ctrl : "+v"(v))
+  if constexpr (NOP) asm volatile("s_nop 1\n\tv_max_f32_dpp %0, %0, %0 " ctrl : : "v"(v));          \
+  else asm volatile("v_max_f32_dpp %0, %0, %0 " ctrl : : "v"(v))
   if constexpr (STEP == 0) { MI_FL_DPP("quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf"); }
   else if constexpr (STEP == 1) { MI_FL_DPP("quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf"); }
   else if constexpr (STEP == 2) { MI_FL_DPP("row_half_mirror row_mask:0xf bank_mask:0xf"); }
@@ -296,6 +317,7 @@ __device__ __forceinline__ void fl_ring_read_v(bf16x8& f, int addr_lo, int addr_
 // whether or not it has anything to wait for (71 of them per streamed tile before).
 template <int WAIT>
 __device__ __forceinline__ void fl_wait_lgkm() {
+  if constexpr (kFlDiag & 16) return;
   if constexpr (WAIT >= 0) asm volatile("s_waitcnt lgkmcnt(%c0)" ::"i"(WAIT) : "memory");
 }
 // The ACCUMULATING form names the accumulator as an input only and writes it behind hipcc's back.  Declared "+v", hipcc
@@ -378,13 +400,17 @@ __device__ __forceinline__ void fl_pin_o(f32x16& v) {
 // Fragment stream of one loop iteration: F[0 .. NK) = row fragments of the NEXT tile (score product, one ds_read_b128
 // each), F[NK .. NK + 2 NT) = transposed fragments of the CURRENT tile (output product, two ds_read_b64_tr_b16 each).
 // lgkmcnt to wait for before the MFMA that consumes F[n] when reads up to F[min(n + AHEAD - 1, last)] have been issued.
-// Waits come in pairs: the MFMA of an even n waits for F[n] AND F[n + 1] (only the reads behind F[n + 1] may be
-// outstanding), the MFMA of an odd n does not wait at all (-1).
+// Waits come in groups of kFlWaitGroup: the MFMA of an n that is a multiple of it waits for F[n] ... F[n + group - 1]
+// (only the reads behind those may be outstanding), the others do not wait at all (-1).
+#ifndef MI_FL_WAIT_GROUP
+#define MI_FL_WAIT_GROUP 2
+#endif
+constexpr int kFlWaitGroup = MI_FL_WAIT_GROUP;
 template <int NS, int NV>
 constexpr int fl_wait_count(int n) {
-  if (n & 1) return -1;
+  if (n % kFlWaitGroup) return -1;
   int c = 0;
-  for (int m = n + 2; m <= n + kFlAhead - 1 && m < NS + NV; ++m) c += m < NS ? 1 : 2;
+  for (int m = n + kFlWaitGroup; m <= n + kFlAhead - 1 && m < NS + NV; ++m) c += m < NS ? 1 : 2;
   return c;
 }
 
@@ -501,9 +527,7 @@ __global__ __launch_bounds__(256, 1) void bilinear_flash_kernel(FlashArgs args) 
   const unsigned vlane_w = vlane ^ (unsigned)(16 * piece_u(C::PIECES * wave));
   auto piece_voff = [&](int i) __attribute__((always_inline)) { return vlane_w ^ (unsigned)(16 * piece_u(i)); };
   auto issue_piece = [&](int t, int i) __attribute__((always_inline)) {
-#ifdef MI_STAMPS
-    if ((args.diag & 1) && t >= 3) return;
-#endif
+    if ((kFlDiag & 1) && t >= 3) return;
     const int q = C::PIECES * wave + i;
     const int stage = t & (kFlStages - 1);
     fl_dma16(piece_voff(i), kv_base + (int64_t)t * C::STAGE + q * 1024, lds0 + stage * C::STAGE + q * 1024);
@@ -542,7 +566,6 @@ __global__ __launch_bounds__(256, 1) void bilinear_flash_kernel(FlashArgs args) 
   float lsum = 0.0f, pos = 0.0f;
   unsigned cnt = 0;                // wave-uniform
   float mref = MI_NEG_INF;         // wave-uniform reference point of the exponentials
-  constexpr float kLog2e = 1.4426950408889634f;
 
   // per-lane constants of the fragment addresses (derivation: DESIGN.md section 4.1, "Fragment addressing"; the same
   // formulas restated in numpy and checked end to end: tests/test_flash_addressing.py)
@@ -572,90 +595,77 @@ __global__ __launch_bounds__(256, 1) void bilinear_flash_kernel(FlashArgs args) 
   f32x16 s_next;   // scores of the newest tile (the score product's accumulator)
   float xs[16];    // the pending tile: prescaled scores (x - m_ref) log2(e), then -- in place -- their exponentials
   float tA = MI_NEG_INF, tB = MI_NEG_INF, off = 0.0f;
-  float tM = MI_NEG_INF;   // masked tiles: lane maximum over the unmasked entries,
-  unsigned mbits = 0u;     // ... bit r set = accumulator element r is masked,
-  bool rare = false;       // ... and the (wave-uniform) flag that the newest tile is such a tile
-  float f_pend = 1.0f;  // a raise of the reference point decided beside the output product is APPLIED to the sums at the
-  bool pend = false;    // next iteration's start, when every product of the old reference point has been issued
+  // wave-uniform values of the reference point, kept per lane (every lane the same number): gfx950 has no scalar float
+  // compare, and selects on SGPR values turn into branches
+  float f_pend = 1.0f;                    // a raise of the reference point decided beside the output product is APPLIED to
+  unsigned long long pendmask = 0;        // the sums at the next iteration's start (pendmask != 0: a finite point was raised)
 
   // ---- softmax of a tile as two lists of micro-ops, each ONE volatile asm statement placed in a chosen MFMA gap.
   // Written as plain C++ in "slices" hipcc undid the placement (ISA of round 2: the sixteen lsum additions sunk into one
   // dependent chain behind the last MFMA, eight of the exponentials and their packing in a single gap, the wave maximum as
   // thirty instructions in another; ~690 cycles per tile that no MFMA hid).  Volatile statements keep their order
   // relative to the MFMAs and reads (which are volatile statements too).
-  //  * HEAD of tile tn (scores in s_next), beside the OUTPUT product of tile tn - 1: mask / positives (rare, C++), lane
-  //    maxima, wave maximum (6 DPP steps), reference-point decision, x = s * log2(e) - m_ref * log2(e) into xs[].
-  //    Writing xs[] here replaces the sixteen register copies "previous = next" of round 2.
+  //  * HEAD of tile tn (scores in s_next), beside the OUTPUT product of tile tn - 1: lane maxima, wave maximum (6 DPP
+  //    steps), reference-point decision, x = s * log2(e) - m_ref * log2(e) into xs[].  Writing xs[] here replaces the
+  //    sixteen register copies "previous = next" of round 2.  NO branch: a branch beside the MFMAs -- above all a TAKEN
+  //    one, which refills the wave's instruction buffer -- cost more than everything else of the softmax together
+  //    (timing experiments of round 3: the head's slots 0 - 10 with their four branches 470 cycles per tile, the sixteen
+  //    exponentials nothing).  Tiles with masked pairs (the diagonal, duplicated study ids: rare) are therefore treated
+  //    as unmasked here and REDONE at the next iteration's start (fix_masked_tile).
   //  * TAIL of tile tp (xs[]), beside the SCORE product of tile tp + 1: p = exp2(x) in place, lsum += p one slot later
   //    (no dependent back-to-back pair: an exponential's consumer needs a wait state), cvt_pk pairs two slots later.
   constexpr int kTailSlots = 17, kHeadSlots = 17;
   auto tail_slot = [&](auto S_) __attribute__((always_inline)) {
     constexpr int sl = decltype(S_)::value;
-#ifdef MI_STAMPS
-    if (args.diag & 2) return;
-#endif
-    if constexpr (sl < 16) fl_v_exp(xs[sl]);
-    if constexpr (sl >= 1 && sl <= 16) fl_v_add(lsum, xs[sl - 1]);
-    if constexpr (GRAD && sl >= 2 && sl <= 16 && sl % 2 == 0) {
+    if constexpr (kFlDiag & 2) return;
+    if constexpr (sl < 16 && !(kFlDiag & 32)) fl_v_exp(xs[sl]);
+    if constexpr (sl >= 1 && sl <= 16 && !(kFlDiag & 64)) fl_v_add(lsum, xs[sl - 1]);
+    if constexpr (GRAD && sl >= 2 && sl <= 16 && sl % 2 == 0 && !(kFlDiag & 128)) {
       constexpr int k = sl / 2 - 1;  // dword k & 3 of fragment k >> 2 = (bf16(p[2k]), bf16(p[2k + 1]))
       pfw[k >> 2][k & 3] = fl_v_cvt_pk(xs[2 * k], xs[2 * k + 1]);
     }
   };
+  // The reference-point decision, branch-free and in ONE statement (lane 63 of `tmaxv` holds the wave maximum):
+  //   raise  = tmax > mref + thr, and not `hold`  (mref = -inf: -inf + thr = -inf, so any finite maximum raises;
+  //            hold = all ones for a tile with masked pairs: its unmasked HEAD must not move the reference point)
+  //   f_pend = exp2((mref - tmax) log2 e)          (meaningful where pendmask: raise with a FINITE old reference point)
+  //   off    = -log2(e) max(mref, -1e30)           (all entries masked so far: x = -inf * c + 1.4e30 = -inf, exp2 gives 0)
+  auto decide = [&](const float& tmaxv, unsigned long long hold) __attribute__((always_inline)) {
+    unsigned long long isninf;
+    float tmax_s, tmax_v;
+    asm volatile(
+        "s_nop 0\n\t"  // (gfx950 wait states the assembler does not pad: VALU write -> v_readlane 1; VALU-written SGPR -> VALU 2)
+        "v_readlane_b32 %[t], %[ta], 63\n\t"
+        "s_nop 1\n\t"
+        "v_mov_b32 %[tv], %[t]\n\t"  // (gfx950: one scalar source per VALU instruction; the select below also reads VCC)
+        "v_add_f32 %[f], 0x41c00000, %[m]\n\t"
+        "v_cmp_gt_f32 vcc, %[tv], %[f]\n\t"
+        "s_andn2_b64 vcc, vcc, %[h]\n\t"
+        "v_sub_f32 %[f], %[m], %[tv]\n\t"
+        "v_mul_f32 %[f], 0x3fb8aa3b, %[f]\n\t"
+        "v_exp_f32 %[f], %[f]\n\t"
+        "v_cmp_class_f32 %[ni], %[m], 4\n\t"
+        "s_andn2_b64 %[pm], vcc, %[ni]\n\t"
+        "v_cndmask_b32 %[m], %[m], %[tv], vcc\n\t"
+        "v_max_f32 %[o], 0xf149f2ca, %[m]\n\t"
+        "v_mul_f32 %[o], 0xbfb8aa3b, %[o]"
+        : [t] "=&s"(tmax_s), [tv] "=&v"(tmax_v), [f] "+v"(f_pend), [ni] "=&s"(isninf), [pm] "+s"(pendmask), [m] "+v"(mref),
+          [o] "+v"(off)  // ("+": written in place, so that the rare second decision of a masked tile adds no copies)
+        : [ta] "v"(tmaxv), [h] "s"(hold)
+        : "vcc");
+    static_assert(kFlThr == 24.0f, "the asm statement above carries the threshold as a literal");
+  };
   // NOPS: the ops run back to back (no MFMA and reads between them): a DPP step then needs two wait states behind the
   // VALU write of its source
-  auto head_slot = [&](auto V_, auto NOPS_, int tn) __attribute__((always_inline)) {
+  auto head_slot = [&](auto V_, auto NOPS_, unsigned long long hold) __attribute__((always_inline)) {
     constexpr int v = decltype(V_)::value;
     constexpr bool NOPS = decltype(NOPS_)::value;
-#ifdef MI_STAMPS
-    if (args.diag & 2) return;
-#endif
+    if constexpr (kFlDiag & 2) return;
+    if constexpr ((kFlDiag & 256) && v <= 10) return;
+    if constexpr ((kFlDiag & 512) && v >= 11) return;
     if constexpr (v == 0) {
       asm volatile("" : "+v"(s_next));  // nothing below reads the scores earlier than this point of the stream
-      // Masked tiles (rare: the diagonal, duplicated study ids) never WRITE the score registers: a C++ write to the MFMA's
-      // accumulator tuple made hipcc build the masked tile in new registers and copy all sixteen in the unmasked path.
-      // Instead the rare path takes its own lane maximum over the unmasked entries (tM replaces the lanes' maxima in slot
-      // 4) and remembers the masked entries as bits; their prescaled scores are set to -inf behind the last slot.
-      if (__builtin_amdgcn_readfirstlane((int)((dupmask >> tn) & 1ull))) {
-        MI_FL_STAMP(5);
-        // some pair of this tile shares a study id (always so on the diagonal): exact 64-bit compares, positives
-        const int64_t* sl = reinterpret_cast<const int64_t*>(smem + C::SID_OFF) + tn * kFlBN + 4 * half;
-        const int d0 = d0_wave - tn * kFlBN;  // streamed row (inside this tile) of stationary row 0's positive
-        if (__builtin_amdgcn_readfirstlane((int)(d0 > -32 && d0 < 32))) {
-          const int want = r32 + d0 - 4 * half;
-#pragma unroll
-          for (int r = 0; r < 16; ++r) pos += (want == (r & 3) + 8 * (r >> 2)) ? s_next[r] : 0.0f;
-        }
-        MI_FL_STAMP(7);
-        tM = MI_NEG_INF;
-        mbits = 0u;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const bool neg = sl[(r & 3) + 8 * (r >> 2)] != sid_i;
-          cnt += (unsigned)__popcll(__ballot(neg));
-          tM = neg ? fmaxf(tM, s_next[r]) : tM;
-          mbits |= neg ? 0u : (1u << r);
-        }
-        rare = true;
-        MI_FL_STAMP(6);
-      } else if (__builtin_amdgcn_readfirstlane((int)((diagmask >> tn) & 1ull))) {
-        // the tile's main diagonal holds this wave's 32 positives and no other pair is masked: streamed row r32 - 4 half
-        // of the lane's column ... i.e. accumulator element (r & 3) + 8 (r >> 2) == r32 - 4 half.  No id loads, a third
-        // of the general path's instructions (whose cold instruction fetch alone cost ~5,000 cycles per occurrence).
-        const int want = r32 - 4 * half;
-        tM = MI_NEG_INF;
-        mbits = 0u;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const bool p = want == (r & 3) + 8 * (r >> 2);
-          pos += p ? s_next[r] : 0.0f;
-          tM = p ? tM : fmaxf(tM, s_next[r]);
-          mbits |= p ? (1u << r) : 0u;
-        }
-        cnt += 1024u - 32u;
-        rare = true;
-      } else {
-        cnt += 1024u;
-      }
+      cnt += 1024u;
       fl_v_max(tA, s_next[0], s_next[1]);
       fl_v_max(tB, s_next[2], s_next[3]);
     } else if constexpr (v >= 1 && v <= 3) {
@@ -663,20 +673,11 @@ __global__ __launch_bounds__(256, 1) void bilinear_flash_kernel(FlashArgs args) 
       fl_v_max3(tB, s_next[4 * v + 2], s_next[4 * v + 3]);
     } else if constexpr (v == 4) {
       fl_v_max(tA, tA, tB);
-      if (rare) tA = tM;
       fl_dpp_max<0, true>(tA);  // (behind the merge: always two wait states)
     } else if constexpr (v >= 5 && v <= 9) {
       fl_dpp_max<v - 4, NOPS>(tA);
     } else if constexpr (v == 10) {
-      const float tmax = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(tA), 63));  // wave-uniform
-      if (tmax > mref + kFlThr || (mref == MI_NEG_INF && tmax > MI_NEG_INF)) {
-        if (mref > MI_NEG_INF) {
-          f_pend = __builtin_amdgcn_exp2f((mref - tmax) * kLog2e);
-          pend = true;
-        }
-        mref = tmax;
-      }
-      off = mref > MI_NEG_INF ? -mref * kLog2e : 0.0f;
+      decide(tA, hold);
     } else if constexpr (v >= 11 && v <= 14) {
       constexpr int r = 3 * (v - 11);
       fl_v_prescale(xs[r], s_next[r], off);
@@ -686,15 +687,81 @@ __global__ __launch_bounds__(256, 1) void bilinear_flash_kernel(FlashArgs args) 
       constexpr int r = 12 + 2 * (v - 15);
       fl_v_prescale(xs[r], s_next[r], off);
       fl_v_prescale(xs[r + 1], s_next[r + 1], off);
-      if constexpr (v == 16) {
-        if (rare) {  // masked entries: -inf, exp2 gives 0
-#pragma unroll
-          for (int q = 0; q < 16; ++q) xs[q] = ((mbits >> q) & 1u) ? MI_NEG_INF : xs[q];
-          rare = false;
-        }
-      }
     }
   };
+  // A tile with masked pairs for this wave's rows, behind its (unmasked) HEAD: count, positives, and the decision and the
+  // prescaling AGAIN with the masked entries left out -- the wave maximum must not see them (a trained critic's positives
+  // sit far above its negatives: a reference point at a positive underflows every negative's exponential).  Rare, runs
+  // on its own at the iteration's start; the scores are still in s_next (the next score chain has not started).
+  auto fix_masked_tile = [&](int tn) __attribute__((always_inline)) {
+    unsigned mbits = 0u;  // bit r: accumulator element r (streamed row (r & 3) + 8 (r >> 2) + 4 half) is masked
+    cnt -= 1024u;
+    const int d0 = d0_wave - tn * kFlBN;  // streamed row (inside this tile) of stationary row 0's positive
+    const int want = r32 + d0 - 4 * half;  // ... of this lane's positive, as an accumulator row index
+    const bool has_pos = want >= 0 && want < 32 && !(want & 4) && d0 > -32 && d0 < 32;
+    const unsigned pbit = has_pos ? 1u << ((want & 3) + 4 * (want >> 3)) : 0u;
+    if (__builtin_amdgcn_readfirstlane((int)((dupmask >> tn) & 1ull))) {
+      MI_FL_STAMP(5);
+      // some pair of this tile shares a study id (always so on the diagonal): exact 64-bit compares, one id at a time
+      // (batched, the sixteen ids are 32 registers this kernel does not have)
+      const int64_t* sl = reinterpret_cast<const int64_t*>(smem + C::SID_OFF) + tn * kFlBN + 4 * half;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const bool neg = sl[(r & 3) + 8 * (r >> 2)] != sid_i;
+        cnt += (unsigned)__popcll(__ballot(neg));
+        mbits |= neg ? 0u : (1u << r);
+        asm volatile("" : "+v"(mbits) : : "memory");  // (one id at a time)
+      }
+      MI_FL_STAMP(6);
+    } else {
+      // only the tile's main diagonal is masked: this wave's 32 positives.  No id loads.
+      mbits = pbit;
+      cnt += 1024u - 32u;
+    }
+    // positives, and the lane maximum over the unmasked entries.  Everything that lives on is changed IN PLACE by asm
+    // statements ("+v"): a new value per path would be a register copy at the join for hipcc, which has none to spare.
+    float tM = MI_NEG_INF;
+    const float ninf = MI_NEG_INF;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      unsigned t;
+      const float sr = s_next[r];
+      // tM = max(tM, masked ? -inf : s);  pos += positive ? s : 0
+      asm volatile("v_and_b32 %[t], %[b], %[mb]\n\t"
+                   "v_cmp_eq_u32 vcc, 0, %[t]\n\t"
+                   "s_nop 1\n\t"  // (VALU-written VCC -> VALU read: two wait states on gfx950)
+                   "v_cndmask_b32 %[t], %[ni], %[s], vcc\n\t"
+                   "v_max_f32 %[tm], %[tm], %[t]\n\t"
+                   "v_and_b32 %[t], %[b], %[pb]\n\t"
+                   "v_cmp_ne_u32 vcc, 0, %[t]\n\t"
+                   "s_nop 1\n\t"
+                   "v_cndmask_b32 %[t], 0, %[s], vcc\n\t"
+                   "v_add_f32 %[p], %[p], %[t]"
+                   : [t] "=&v"(t), [tm] "+v"(tM), [p] "+v"(pos)
+                   : [b] "n"(1 << r), [mb] "v"(mbits), [pb] "v"(pbit), [s] "v"(sr), [ni] "v"(ninf)
+                   : "vcc");
+    }
+    float tmaxv = wave_max_uniform(tM);
+    asm volatile("s_nop 1" : "+v"(tmaxv));
+    decide(tmaxv, 0ull);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      unsigned t;
+      const float sr = s_next[r];
+      // x = masked ? -inf : s * log2(e) + off   (exp2 then gives 0)
+      asm volatile("v_fmamk_f32 %[x], %[s], 0x3fb8aa3b, %[o]\n\t"
+                   "v_and_b32 %[t], %[b], %[mb]\n\t"
+                   "v_cmp_eq_u32 vcc, 0, %[t]\n\t"
+                   "s_nop 1\n\t"
+                   "v_cndmask_b32 %[x], %[ni], %[x], vcc"
+                   : [x] "+v"(xs[r]), [t] "=&v"(t)
+                   : [b] "n"(1 << r), [mb] "v"(mbits), [s] "v"(sr), [o] "v"(off), [ni] "v"(ninf)
+                   : "vcc");
+    }
+  };
+
+  // does tile t hold masked pairs for this wave's rows?  (wave-uniform; the waves of a workgroup may differ)
+  const unsigned long long spmask = dupmask | diagmask;
 
   // ---- one loop iteration: [score product of tile tn = tp + 1 (HAS_S)] with the TAIL of tile tp in its MFMA gaps, then
   // [output product of tile tp (HAS_V)] with, in its gaps, the HEAD of tile tn and the LDS-DMA pieces of tile tp + 3.
@@ -703,6 +770,26 @@ __global__ __launch_bounds__(256, 1) void bilinear_flash_kernel(FlashArgs args) 
     constexpr bool HAS_S = decltype(HAS_S_)::value, HAS_V = decltype(HAS_V_)::value && GRAD;
     constexpr bool DO_TAIL = decltype(HAS_V_)::value;  // a finished tile is waiting for its exponentials
     constexpr int NS = HAS_S ? C::NK : 0, NV = HAS_V ? 2 * C::NT : 0, NF = NS + NV;
+    // all ones when the tile whose HEAD this iteration carries (tp + 1) holds masked pairs: its unmasked HEAD then leaves
+    // the reference point alone (fix_masked_tile decides at the next iteration's start)
+    const unsigned long long hold_next = 0ull - ((spmask >> ((tp + 1) & 63)) & 1ull);
+    // The two rare events of the previous HEAD (tile tp), behind ONE test in the common path:
+    //  * tile tp holds masked pairs: its decision and prescaling are redone (fix_masked_tile);
+    //  * a raise of a finite reference point: every sum still stands at the old point (this tile's exponentials, taken
+    //    against the new one, have not been added yet) -- applied here, when every product of the old point is issued.
+    // (first thing of the iteration: before the fragment addresses and the first reads are live)
+    fl_v_opaque(lsum);
+    if constexpr (DO_TAIL && !(kFlDiag & 2)) {
+      if (__builtin_expect(pendmask != 0, 0)) {
+        lsum *= f_pend;
+        fl_v_opaque(lsum);
+        if constexpr (GRAD) {
+          fl_mfma_drain_all();
+          fl_static_for<0, C::NT>([&](auto CT) __attribute__((always_inline)) { fl_scale_tile<(decltype(CT)::value < C::OA)>(o[decltype(CT)::value], f_pend); });
+        }
+        pendmask = 0;
+      }
+    }
     const int so = ((tp + 1) & (kFlStages - 1)) * C::STAGE + a0_lane;  // row reads of tile tp + 1
     const int vo = (tp & (kFlStages - 1)) * C::STAGE + a1_lane;       // transposed reads of tile tp
     int abase[8], tbase[8];
@@ -716,6 +803,7 @@ __global__ __launch_bounds__(256, 1) void bilinear_flash_kernel(FlashArgs args) 
     }
     auto issue_read = [&](auto NI) __attribute__((always_inline)) {
       constexpr int n = decltype(NI)::value;
+      if constexpr (kFlDiag & 8) return;
       if constexpr (n < NS) {
         fl_ring_read_s<n % kFlRing, 256 * (n >> 3)>(ring[n % kFlRing], abase[n & 7]);
       } else if constexpr (n < NF) {
@@ -725,16 +813,6 @@ __global__ __launch_bounds__(256, 1) void bilinear_flash_kernel(FlashArgs args) 
       }
     };
     fl_static_for<0, kFlAhead>([&](auto NI) __attribute__((always_inline)) { issue_read(NI); });
-    // a raise of the reference point decided during the previous output product: every sum still stands at the old point
-    // (this tile's exponentials, taken against the new one, have not been added yet)
-    if (pend) {
-      lsum *= f_pend;
-      if constexpr (GRAD) {
-        fl_mfma_drain_all();
-        fl_static_for<0, C::NT>([&](auto CT) __attribute__((always_inline)) { fl_scale_tile<(decltype(CT)::value < C::OA)>(o[decltype(CT)::value], f_pend); });
-      }
-      pend = false;
-    }
     __builtin_amdgcn_sched_barrier(0);
     // score product; the TAIL slots spread over its gaps in order
     fl_static_for<0, NS>([&](auto NI) __attribute__((always_inline)) {
@@ -756,15 +834,18 @@ __global__ __launch_bounds__(256, 1) void bilinear_flash_kernel(FlashArgs args) 
     if constexpr (HAS_S && !HAS_V) {
       // no output product to carry the new tile's HEAD (the pipeline's first tile; the forward-only kernel)
       fl_score_fence<true>(s_next);
-      fl_static_for<0, kHeadSlots>([&](auto VI) __attribute__((always_inline)) { head_slot(VI, std::true_type{}, tp + 1); });
+      fl_static_for<0, kHeadSlots>([&](auto VI) __attribute__((always_inline)) { head_slot(VI, std::true_type{}, hold_next); });
       __builtin_amdgcn_sched_barrier(0);
     }
     // output product + HEAD of the next tile + LDS-DMA issue for tile tp + 3
     if constexpr (HAS_V) {
       constexpr int EVERY = NV / C::PIECES;
-      const bool more = tp + 3 < nt;
-      // scalar bases of tile tp + 3 for this wave's pieces (uniform by construction; readfirstlane proves it to hipcc)
-      const uintptr_t gb = (uintptr_t)(kv_base + (int64_t)(tp + 3) * C::STAGE + wave * (C::PIECES * 1024));
+      // The pieces of tile tp + 3 are issued UNCONDITIONALLY: behind the last tile the source index is clamped (the stage
+      // they land in belongs to tile tp - 1, which nobody reads again), so that no gap carries a branch and the counted
+      // waits of the loop are the same in every iteration.  At most two tiles per workgroup are fetched for nothing.
+      const int tq = tp + 3 < nt ? tp + 3 : nt - 1;
+      // scalar bases of that tile for this wave's pieces (uniform by construction; readfirstlane proves it to hipcc)
+      const uintptr_t gb = (uintptr_t)(kv_base + (int64_t)tq * C::STAGE + wave * (C::PIECES * 1024));
       const unsigned gb_lo = __builtin_amdgcn_readfirstlane((unsigned)gb);  // (the builtin returns int: keep the halves
       const unsigned gb_hi = __builtin_amdgcn_readfirstlane((unsigned)(gb >> 32));  // unsigned, or the low one sign-extends)
       const void* sb0 = (const void*)(((uintptr_t)gb_hi << 32) | gb_lo);
@@ -785,23 +866,25 @@ __global__ __launch_bounds__(256, 1) void bilinear_flash_kernel(FlashArgs args) 
           constexpr int k = (u - U0) - (u / EVERY - U0 / EVERY);  // index among the available gaps
           constexpr int lo = k * kHeadSlots / n_avail, hi = (k + 1) * kHeadSlots / n_avail;
           constexpr bool nops = kHeadSlots > n_avail;  // several slots share a gap
-          fl_static_for<lo, hi>([&](auto VI) __attribute__((always_inline)) { head_slot(VI, std::integral_constant<bool, nops>{}, tp + 1); });
+          fl_static_for<lo, hi>([&](auto VI) __attribute__((always_inline)) { head_slot(VI, std::integral_constant<bool, nops>{}, hold_next); });
         }
-        if constexpr (dma_gap) {
+        // M0 (the pieces' LDS base) changes with i & ~3: set it two gaps ahead of pieces 0 and 4
+        if constexpr (HAS_S && !(kFlDiag & 1) && u % EVERY == EVERY - 3 && ((u / EVERY) & 3) == 0 && u / EVERY < C::PIECES)
+          fl_dma_set_m0<((u / EVERY) & ~3) * 1024>(lb);
+        if constexpr (dma_gap && HAS_S && !(kFlDiag & 1)) {  // (not behind the last tile: no barrier protects its stage)
           constexpr int i = u / EVERY;
-          if (more) {
-#ifdef MI_STAMPS
-            if (!(args.diag & 1))
-#endif
-            fl_dma16_at<(i & ~3) * 1024, (i & 3) * 1024,
-                        16 * (C::RPP == 1 ? fl_swz(i) : (C::RPP == 2 ? (8 * (i & 1)) | ((i >> 1) & 3) : (i & 3)))>(
-                vlane_w, i < 4 ? sb0 : sb1, lb);
-          }
+          fl_dma16_at<(i & 3) * 1024,
+                      16 * (C::RPP == 1 ? fl_swz(i) : (C::RPP == 2 ? (8 * (i & 1)) | ((i >> 1) & 3) : (i & 3)))>(
+              vlane_w, i < 4 ? sb0 : sb1);
         }
         __builtin_amdgcn_sched_barrier(0);
       });
     } else if constexpr (DO_TAIL) {
       if (tp + 3 < nt) issue_tile(tp + 3);
+    }
+    // the tile whose HEAD just ran holds masked pairs for this wave's rows (rare): redo its decision and prescaling
+    if constexpr (HAS_S && !(kFlDiag & 2)) {
+      if (__builtin_expect(hold_next != 0, 0)) fix_masked_tile(tp + 1);
     }
   };
   using T_ = std::true_type;
@@ -814,11 +897,9 @@ __global__ __launch_bounds__(256, 1) void bilinear_flash_kernel(FlashArgs args) 
       if (t == nt / 2) MI_FL_STAMP(2);
       // tile t + 1 must have landed (own pieces, then everybody's); every wave is done with tile t - 1, whose stage the
       // pieces issued in this iteration refill.  Outstanding here: tiles t + 1 and t + 2.
-#ifdef MI_STAMPS
-      if (args.diag & 4) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      else
-#endif
-      if (t + 2 < nt) fl_wait_vmcnt_barrier<C::PIECES>();
+      if constexpr (kFlDiag & 4) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      else if constexpr (GRAD) fl_wait_vmcnt_barrier<C::PIECES>();  // (pieces are issued in every iteration: see there)
+      else if (t + 2 < nt) fl_wait_vmcnt_barrier<C::PIECES>();
       else fl_wait_vmcnt_barrier<0>();
       if (t == nt / 2) MI_FL_STAMP(3);
       iteration(T_{}, T_{}, t);
@@ -830,6 +911,8 @@ __global__ __launch_bounds__(256, 1) void bilinear_flash_kernel(FlashArgs args) 
   MI_FL_STAMP(9);
 
   // ---- records and partial sums
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the clamped pieces of the last iterations: nobody reads them)
+  fl_v_opaque(lsum);
   lsum = wave_sum(lsum);
   pos = wave_sum(pos);
   if (lane == 0) {
@@ -1158,9 +1241,6 @@ static inline int launch_flash(FlashArgs a, int64_t d, bool grad, hipStream_t st
   int combos = a.p[0].n_split + (a.n_problems == 2 ? a.p[1].n_split : 0);
   a.n_combo = (combos + 7) / 8 * 8;
   a.diag = 0;
-#ifdef MI_STAMPS
-  if (const char* e = getenv("MI_FLASH_DIAG")) a.diag = atoi(e);
-#endif
   static const int no_index_mask = getenv("MI_FLASH_NO_INDEX_MASK") ? 1 : 0;  // A/B switch
   a.no_index_mask = no_index_mask;
   static const int xcd_rows = getenv("MI_FLASH_XCD_COMBO") ? 0 : 1;  // A/B switch

@@ -2,7 +2,7 @@
    MI_STAMP_KERNEL="fused S" python tools/diag/stamps_flash.py"""
 import os, sys
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..")
-os.environ["MI_CRITIC_LIB"] = os.path.join(ROOT, "mutual-information-multimodal_amd", "lib_stamps", "libmi_critic_hip.so")
+os.environ.setdefault("MI_CRITIC_LIB", os.path.join(ROOT, "mutual-information-multimodal_amd", "lib_stamps", "libmi_critic_hip.so"))
 os.environ.setdefault("MI_STAMP_KERNEL", "fused S")
 sys.path.insert(0, os.path.join(ROOT, "mutual-information-multimodal_amd"))
 sys.path.insert(0, ROOT)
