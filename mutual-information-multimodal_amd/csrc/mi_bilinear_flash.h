@@ -63,7 +63,11 @@ constexpr int kFlDiag = MI_FL_DIAG;
 constexpr int kFlRows = 128;     // stationary rows per workgroup
 constexpr int kFlBN = 32;        // streamed rows per tile
 constexpr int kFlStages = 4;     // LDS stages (three tiles in flight)
-constexpr float kFlThr = 24.0f;  // raise the reference point when a tile maximum exceeds it by this much
+// raise the reference point when a tile maximum exceeds it by this much.  exp(60) = 1e26: the exponentials are bf16 (fp32's
+// exponent range), the sums fp32 (<= 1e26 * 4096 * |operand|), the slabs carry a per-wave power-of-two scale.  Every raise
+// costs a drain of the matrix pipe and ~260 multiplications; at 24 a batch with score deviations of ~20 (the benchmark's)
+// raised several times per workgroup.
+constexpr float kFlThr = 60.0f;
 constexpr int kFlMaxTilesPerSplit = 64;  // streamed study ids of a split sit in LDS: 64 tiles x 32 x 8 bytes = 16 KB
 
 struct FlashProblem {
@@ -597,8 +601,8 @@ __global__ __launch_bounds__(256, 1) void bilinear_flash_kernel(FlashArgs args) 
   float tA = MI_NEG_INF, tB = MI_NEG_INF, off = 0.0f;
   // wave-uniform values of the reference point, kept per lane (every lane the same number): gfx950 has no scalar float
   // compare, and selects on SGPR values turn into branches
-  float f_pend = 1.0f;                    // a raise of the reference point decided beside the output product is APPLIED to
-  unsigned long long pendmask = 0;        // the sums at the next iteration's start (pendmask != 0: a finite point was raised)
+  float f_pend = 1.0f;  // a raise of the reference point decided beside the output product is APPLIED to the sums at the
+                        // next iteration's start (f_pend != 1: exp(old - new)); every lane the same value
 
   // ---- softmax of a tile as two lists of micro-ops, each ONE volatile asm statement placed in a chosen MFMA gap.
   // Written as plain C++ in "slices" hipcc undid the placement (ISA of round 2: the sixteen lsum additions sunk into one
@@ -625,44 +629,48 @@ __global__ __launch_bounds__(256, 1) void bilinear_flash_kernel(FlashArgs args) 
       pfw[k >> 2][k & 3] = fl_v_cvt_pk(xs[2 * k], xs[2 * k + 1]);
     }
   };
-  // The reference-point decision, branch-free and in ONE statement (lane 63 of `tmaxv` holds the wave maximum):
-  //   raise  = tmax > mref + thr, and not `hold`  (mref = -inf: -inf + thr = -inf, so any finite maximum raises;
-  //            hold = all ones for a tile with masked pairs: its unmasked HEAD must not move the reference point)
-  //   f_pend = exp2((mref - tmax) log2 e)          (meaningful where pendmask: raise with a FINITE old reference point)
-  //   off    = -log2(e) max(mref, -1e30)           (all entries masked so far: x = -inf * c + 1.4e30 = -inf, exp2 gives 0)
-  auto decide = [&](const float& tmaxv, unsigned long long hold) __attribute__((always_inline)) {
-    unsigned long long isninf;
-    float tmax_s, tmax_v;
+  // The reference-point decision, branch-free, in ONE statement and -- behind the v_readlane that broadcasts the wave
+  // maximum (lane 63 of `tmaxv`) -- on the vector unit only: every hand-over between the vector and the scalar unit
+  // (v_cmp -> s_and, SALU-written VCC -> v_cndmask) stalls the one wave on its SIMD for tens of cycles.
+  //   raise  = tmax > mref + thr      (mref = -inf: -inf + thr = -inf, so any finite maximum raises; thr = +inf for a
+  //            tile with masked pairs: its unmasked HEAD must not move the reference point)
+  //   f_pend = raise, from a FINITE reference point ? exp2((mref - tmax) log2 e) : 1     (1: nothing to rescale)
+  //   off    = -log2(e) max(mref, -1e30)  (all entries masked so far: x = -inf * c + 1.4e30 = -inf, exp2 gives 0)
+  auto decide = [&](const float& tmaxv, float thr) __attribute__((always_inline)) {
+    float tmax_s, tmax_v, m_old;
     asm volatile(
-        "s_nop 0\n\t"  // (gfx950 wait states the assembler does not pad: VALU write -> v_readlane 1; VALU-written SGPR -> VALU 2)
-        "v_readlane_b32 %[t], %[ta], 63\n\t"
-        "s_nop 1\n\t"
-        "v_mov_b32 %[tv], %[t]\n\t"  // (gfx950: one scalar source per VALU instruction; the select below also reads VCC)
-        "v_add_f32 %[f], 0x41c00000, %[m]\n\t"
+        "s_nop 0\n\t"  // (gfx950 wait states the assembler does not pad: VALU write -> v_readlane 1; VALU-written SGPR /
+        "v_readlane_b32 %[t], %[ta], 63\n\t"  //  VCC -> VALU read 2)
+        "v_mov_b32 %[mo], %[m]\n\t"
+        "v_add_f32 %[f], %[th], %[m]\n\t"
+        "v_mov_b32 %[tv], %[t]\n\t"
         "v_cmp_gt_f32 vcc, %[tv], %[f]\n\t"
-        "s_andn2_b64 vcc, vcc, %[h]\n\t"
         "v_sub_f32 %[f], %[m], %[tv]\n\t"
         "v_mul_f32 %[f], 0x3fb8aa3b, %[f]\n\t"
         "v_exp_f32 %[f], %[f]\n\t"
-        "v_cmp_class_f32 %[ni], %[m], 4\n\t"
-        "s_andn2_b64 %[pm], vcc, %[ni]\n\t"
         "v_cndmask_b32 %[m], %[m], %[tv], vcc\n\t"
+        "s_nop 0\n\t"  // (the exponential's consumer)
+        "v_cndmask_b32 %[f], 1.0, %[f], vcc\n\t"
+        "v_cmp_class_f32 vcc, %[mo], 4\n\t"
         "v_max_f32 %[o], 0xf149f2ca, %[m]\n\t"
-        "v_mul_f32 %[o], 0xbfb8aa3b, %[o]"
-        : [t] "=&s"(tmax_s), [tv] "=&v"(tmax_v), [f] "+v"(f_pend), [ni] "=&s"(isninf), [pm] "+s"(pendmask), [m] "+v"(mref),
+        "v_mul_f32 %[o], 0xbfb8aa3b, %[o]\n\t"
+        "v_cndmask_b32 %[f], %[f], 1.0, vcc"
+        : [t] "=&s"(tmax_s), [tv] "=&v"(tmax_v), [mo] "=&v"(m_old), [f] "+v"(f_pend), [m] "+v"(mref),
           [o] "+v"(off)  // ("+": written in place, so that the rare second decision of a masked tile adds no copies)
-        : [ta] "v"(tmaxv), [h] "s"(hold)
+        : [ta] "v"(tmaxv), [th] "s"(thr)
         : "vcc");
-    static_assert(kFlThr == 24.0f, "the asm statement above carries the threshold as a literal");
   };
   // NOPS: the ops run back to back (no MFMA and reads between them): a DPP step then needs two wait states behind the
   // VALU write of its source
-  auto head_slot = [&](auto V_, auto NOPS_, unsigned long long hold) __attribute__((always_inline)) {
+  auto head_slot = [&](auto V_, auto NOPS_, float thr) __attribute__((always_inline)) {
     constexpr int v = decltype(V_)::value;
     constexpr bool NOPS = decltype(NOPS_)::value;
     if constexpr (kFlDiag & 2) return;
     if constexpr ((kFlDiag & 256) && v <= 10) return;
     if constexpr ((kFlDiag & 512) && v >= 11) return;
+    if constexpr ((kFlDiag & 1024) && v <= 3) return;             // ... no lane maxima
+    if constexpr ((kFlDiag & 2048) && v >= 4 && v <= 9) return;   // ... no wave maximum
+    if constexpr ((kFlDiag & 4096) && v == 10) return;            // ... no decision
     if constexpr (v == 0) {
       asm volatile("" : "+v"(s_next));  // nothing below reads the scores earlier than this point of the stream
       cnt += 1024u;
@@ -677,7 +685,7 @@ __global__ __launch_bounds__(256, 1) void bilinear_flash_kernel(FlashArgs args) 
     } else if constexpr (v >= 5 && v <= 9) {
       fl_dpp_max<v - 4, NOPS>(tA);
     } else if constexpr (v == 10) {
-      decide(tA, hold);
+      decide(tA, thr);
     } else if constexpr (v >= 11 && v <= 14) {
       constexpr int r = 3 * (v - 11);
       fl_v_prescale(xs[r], s_next[r], off);
@@ -695,6 +703,8 @@ __global__ __launch_bounds__(256, 1) void bilinear_flash_kernel(FlashArgs args) 
   // on its own at the iteration's start; the scores are still in s_next (the next score chain has not started).
   auto fix_masked_tile = [&](int tn) __attribute__((always_inline)) {
     unsigned mbits = 0u;  // bit r: accumulator element r (streamed row (r & 3) + 8 (r >> 2) + 4 half) is masked
+    float tq;
+    unsigned long long m1;
     cnt -= 1024u;
     const int d0 = d0_wave - tn * kFlBN;  // streamed row (inside this tile) of stationary row 0's positive
     const int want = r32 + d0 - 4 * half;  // ... of this lane's positive, as an accumulator row index
@@ -718,10 +728,45 @@ __global__ __launch_bounds__(256, 1) void bilinear_flash_kernel(FlashArgs args) 
       mbits = pbit;
       cnt += 1024u - 32u;
     }
-    // positives, and the lane maximum over the unmasked entries.  Everything that lives on is changed IN PLACE by asm
-    // statements ("+v"): a new value per path would be a register copy at the join for hipcc, which has none to spare.
-    float tM = MI_NEG_INF;
+    // Everything that lives on is changed IN PLACE by asm statements ("+v"): a new value per path would be a register
+    // copy at the join for hipcc, which has none to spare.
     const float ninf = MI_NEG_INF;
+    // (1) the positives.  (2) Did the unmasked HEAD see a maximum that WOULD have raised the reference point?  (tA still
+    // holds the wave maximum over ALL entries in lane 63.)  If not -- the usual case: an untrained critic's positives look
+    // like its negatives, and a trained one's reference point already sits high -- the prescaled scores of the unmasked
+    // entries stand as the HEAD wrote them and only the masked ones are set to -inf.
+    const float tmax_all = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(tA), 63));
+    const bool redo = __builtin_amdgcn_readfirstlane((int)(tmax_all > mref + kFlThr || mref == MI_NEG_INF)) != 0;
+    if (!redo) {
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) {
+        unsigned t, u;
+        const float s0 = s_next[r], s1 = s_next[r + 1];
+        // pos += positive ? s : 0;  x = masked ? -inf : x   (two elements per statement: each compare's two wait states
+        // are the other element's instructions)
+        asm volatile("v_and_b32 %[t], %[b0], %[pb]\n\t"
+                     "v_and_b32 %[u], %[b1], %[pb]\n\t"
+                     "v_cmp_ne_u32 vcc, 0, %[t]\n\t"
+                     "v_cmp_ne_u32 %[m1], 0, %[u]\n\t"
+                     "v_and_b32 %[t], %[b0], %[mb]\n\t"
+                     "v_and_b32 %[u], %[b1], %[mb]\n\t"
+                     "v_cndmask_b32 %[q], 0, %[s0], vcc\n\t"
+                     "v_add_f32 %[p], %[p], %[q]\n\t"
+                     "v_cndmask_b32 %[q], 0, %[s1], %[m1]\n\t"
+                     "v_add_f32 %[p], %[p], %[q]\n\t"
+                     "v_cmp_ne_u32 vcc, 0, %[t]\n\t"
+                     "v_cmp_ne_u32 %[m1], 0, %[u]\n\t"
+                     "s_nop 1\n\t"
+                     "v_cndmask_b32 %[x0], %[x0], %[ni], vcc\n\t"
+                     "v_cndmask_b32 %[x1], %[x1], %[ni], %[m1]"
+                     : [t] "=&v"(t), [u] "=&v"(u), [q] "=&v"(tq), [m1] "=&s"(m1), [p] "+v"(pos), [x0] "+v"(xs[r]), [x1] "+v"(xs[r + 1])
+                     : [b0] "n"(1 << r), [b1] "n"(2 << r), [mb] "v"(mbits), [pb] "v"(pbit), [s0] "v"(s0), [s1] "v"(s1), [ni] "v"(ninf)
+                     : "vcc");
+      }
+      return;
+    }
+    // the full redo: lane maximum over the unmasked entries, wave maximum, decision, prescaling
+    float tM = MI_NEG_INF;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       unsigned t;
@@ -743,7 +788,7 @@ __global__ __launch_bounds__(256, 1) void bilinear_flash_kernel(FlashArgs args) 
     }
     float tmaxv = wave_max_uniform(tM);
     asm volatile("s_nop 1" : "+v"(tmaxv));
-    decide(tmaxv, 0ull);
+    decide(tmaxv, kFlThr);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       unsigned t;
@@ -770,24 +815,24 @@ __global__ __launch_bounds__(256, 1) void bilinear_flash_kernel(FlashArgs args) 
     constexpr bool HAS_S = decltype(HAS_S_)::value, HAS_V = decltype(HAS_V_)::value && GRAD;
     constexpr bool DO_TAIL = decltype(HAS_V_)::value;  // a finished tile is waiting for its exponentials
     constexpr int NS = HAS_S ? C::NK : 0, NV = HAS_V ? 2 * C::NT : 0, NF = NS + NV;
-    // all ones when the tile whose HEAD this iteration carries (tp + 1) holds masked pairs: its unmasked HEAD then leaves
-    // the reference point alone (fix_masked_tile decides at the next iteration's start)
-    const unsigned long long hold_next = 0ull - ((spmask >> ((tp + 1) & 63)) & 1ull);
-    // The two rare events of the previous HEAD (tile tp), behind ONE test in the common path:
-    //  * tile tp holds masked pairs: its decision and prescaling are redone (fix_masked_tile);
-    //  * a raise of a finite reference point: every sum still stands at the old point (this tile's exponentials, taken
+    // the tile whose HEAD this iteration carries (tp + 1) holds masked pairs for this wave's rows: its unmasked HEAD then
+    // leaves the reference point alone (threshold +inf) and fix_masked_tile decides at the iteration's end
+    const bool masked_next = __builtin_amdgcn_readfirstlane((int)((spmask >> ((tp + 1) & 63)) & 1ull)) != 0;
+    const float thr_next = masked_next ? __builtin_inff() : kFlThr;
+    // A raise of a finite reference point by the previous HEAD: every sum still stands at the old point (this tile's exponentials, taken
     //    against the new one, have not been added yet) -- applied here, when every product of the old point is issued.
     // (first thing of the iteration: before the fragment addresses and the first reads are live)
     fl_v_opaque(lsum);
     if constexpr (DO_TAIL && !(kFlDiag & 2)) {
-      if (__builtin_expect(pendmask != 0, 0)) {
+      if (__builtin_expect(__builtin_amdgcn_readfirstlane((int)__float_as_uint(f_pend)) != 0x3f800000, 0)) {
         lsum *= f_pend;
         fl_v_opaque(lsum);
         if constexpr (GRAD) {
           fl_mfma_drain_all();
           fl_static_for<0, C::NT>([&](auto CT) __attribute__((always_inline)) { fl_scale_tile<(decltype(CT)::value < C::OA)>(o[decltype(CT)::value], f_pend); });
         }
-        pendmask = 0;
+        f_pend = 1.0f;
+        fl_v_opaque(f_pend);
       }
     }
     const int so = ((tp + 1) & (kFlStages - 1)) * C::STAGE + a0_lane;  // row reads of tile tp + 1
@@ -834,7 +879,7 @@ __global__ __launch_bounds__(256, 1) void bilinear_flash_kernel(FlashArgs args) 
     if constexpr (HAS_S && !HAS_V) {
       // no output product to carry the new tile's HEAD (the pipeline's first tile; the forward-only kernel)
       fl_score_fence<true>(s_next);
-      fl_static_for<0, kHeadSlots>([&](auto VI) __attribute__((always_inline)) { head_slot(VI, std::true_type{}, hold_next); });
+      fl_static_for<0, kHeadSlots>([&](auto VI) __attribute__((always_inline)) { head_slot(VI, std::true_type{}, thr_next); });
       __builtin_amdgcn_sched_barrier(0);
     }
     // output product + HEAD of the next tile + LDS-DMA issue for tile tp + 3
@@ -866,7 +911,7 @@ __global__ __launch_bounds__(256, 1) void bilinear_flash_kernel(FlashArgs args) 
           constexpr int k = (u - U0) - (u / EVERY - U0 / EVERY);  // index among the available gaps
           constexpr int lo = k * kHeadSlots / n_avail, hi = (k + 1) * kHeadSlots / n_avail;
           constexpr bool nops = kHeadSlots > n_avail;  // several slots share a gap
-          fl_static_for<lo, hi>([&](auto VI) __attribute__((always_inline)) { head_slot(VI, std::integral_constant<bool, nops>{}, hold_next); });
+          fl_static_for<lo, hi>([&](auto VI) __attribute__((always_inline)) { head_slot(VI, std::integral_constant<bool, nops>{}, thr_next); });
         }
         // M0 (the pieces' LDS base) changes with i & ~3: set it two gaps ahead of pieces 0 and 4
         if constexpr (HAS_S && !(kFlDiag & 1) && u % EVERY == EVERY - 3 && ((u / EVERY) & 3) == 0 && u / EVERY < C::PIECES)
@@ -884,7 +929,7 @@ __global__ __launch_bounds__(256, 1) void bilinear_flash_kernel(FlashArgs args) 
     }
     // the tile whose HEAD just ran holds masked pairs for this wave's rows (rare): redo its decision and prescaling
     if constexpr (HAS_S && !(kFlDiag & 2)) {
-      if (__builtin_expect(hold_next != 0, 0)) fix_masked_tile(tp + 1);
+      if (__builtin_expect(masked_next, 0)) fix_masked_tile(tp + 1);
     }
   };
   using T_ = std::true_type;
@@ -911,7 +956,8 @@ __global__ __launch_bounds__(256, 1) void bilinear_flash_kernel(FlashArgs args) 
   MI_FL_STAMP(9);
 
   // ---- records and partial sums
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the clamped pieces of the last iterations: nobody reads them)
+  // (the clamped pieces of the last iterations may still be in flight: nobody reads them, and s_endpgm waits for every
+  // counter before the workgroup's LDS is released)
   fl_v_opaque(lsum);
   lsum = wave_sum(lsum);
   pos = wave_sum(pos);
