@@ -164,6 +164,8 @@ def kernel_flops(name, br, b, d_img, d_txt, h1=1024, h2=512):
             return 2.0 * br * b * d_txt
         if "from the fused sums" in name:
             return 0.0
+        if "sums ->" in name:  # partial sums -> dT, dY fused with dX = dT W^T
+            return 2.0 * br * d_img * d_txt
         if "dW" in name and "|" in name:  # two-problem launch: dW = X^T dT and dX = dT W^T
             return 4.0 * br * d_img * d_txt
         if "|" in name:  # two-problem launch: dT = G Y and dY = G^T T
@@ -246,8 +248,7 @@ class Stepper:
         o = self.step_obj
         if self.dist_mode:
             return o.step_eager()
-        o._fwd()
-        o._bwd()
+        o._step()  # one C-ABI call for the bilinear critic (mi_bilinear_step), forward + backward calls otherwise
         return o.loss_buf
 
     def loss(self):

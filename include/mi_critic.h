@@ -82,7 +82,7 @@ typedef struct mi_stats {
   int64_t reserved2, reserved3;
 } mi_stats;
 
-int mi_abi_version(void);
+int mi_abi_version(void);  /* 3: mi_bilinear_step added */
 const char* mi_last_error(void);
 
 /* Optional per-kernel timing (bench.py's roofline leg): between mi_profile_begin and mi_profile_end every kernel
@@ -149,6 +149,18 @@ int mi_bilinear_bwd(const float* x, const float* y, const float* w, const int64_
                     int64_t d_txt, int precision, const mi_stats* stats, const float* grad_out, float* grad_x,
                     float* grad_y, float* grad_w, void* workspace, size_t workspace_bytes,
                     int workspace_from_forward, void* stream);
+
+/* One critic step in ONE call (single GPU; the sharded case needs the cross-rank merge between the forward and the
+ * backward and uses the two calls above): forward, statistics, loss and every gradient of  grad_out[0] * loss
+ * (grad_out == NULL: 1).  Same inputs, outputs and workspace as mi_bilinear_fwd + mi_bilinear_bwd with b_rows == b,
+ * row_offset == 0; replaces the whole call site main_utils.py:220-226 (pairs -> critic -> bound -> loss.backward()).
+ * Where the fused kernels take the shape it saves the finalize launch: nothing needs the loss between the fused B x B
+ * kernel and the gradients, so the per-wave records are merged by the launch that also turns the partial sums into
+ * dT / grad_y / grad_x.  loss_out, *stats and partials_out (optional) are valid when the call's work has completed. */
+int mi_bilinear_step(const float* x, const float* y, const float* w, const int64_t* sid, int64_t b, int64_t d_img,
+                     int64_t d_txt, int estimator, int precision, const float* grad_out, float* loss_out,
+                     mi_stats* stats, float* partials_out, float* grad_x, float* grad_y, float* grad_w, void* workspace,
+                     size_t workspace_bytes, void* stream);
 
 /* ---- fused separable critic: S = (X Wg)(Y Wh)^T, bound, all gradients ------------------------------- */
 /* BASELINE.json configs[1] (an extension: the reference has no separable critic; bound, masking and pair semantics are

@@ -16,6 +16,7 @@
 #include "mi_gemm.h"
 #include "mi_gemm_bf16.h"
 #include "mi_bilinear_flash.h"
+#include "mi_bilinear_tail.h"
 #include "mi_fp8.h"
 
 namespace mi {
@@ -42,6 +43,9 @@ struct BilinearPlan {
   Partial* fl_rec[2];
   unsigned char* fl_dup[2];  // equal-id flags per 32 x 32 block: [br / 32][b / 32] and its transpose
   bf16_t *tfb, *yfb;         // fragment-major copies of T and Y: the stationary operands of the fused kernel
+  // the backward's tail (mi_bilinear_tail.h): fragment-major W (B operand of dX = dT W^T), X^T and dT^T (operands of dW)
+  bool tail;
+  bf16_t *wfb, *xtfb, *dttfb;
   // bf16x3 (MI_PREC_BF16X3): every bf16 operand copy holds hi and lo parts along a tripled K (mi_gemm_bf16.h,
   // split3_offsets); A-side role: xb, xtb, tb, gb, gtb, dtb; B-side role: yb, ytb, wb, wtb, ttb, dttb
   int x3;  // 3 in that mode, else 1
@@ -92,6 +96,11 @@ static BilinearPlan plan_bilinear(Workspace& ws, int64_t br, int64_t b, int64_t 
   }
   p.tfb = p.fl.ok ? ws.take<bf16_t>(br * dy) : nullptr;
   p.yfb = p.fl.ok ? ws.take<bf16_t>(b * dy) : nullptr;
+  static const bool no_tail = getenv("MI_NO_TAIL") != nullptr;  // A/B switch: the round-2 backward tail (three launches)
+  p.tail = p.fl.ok && !no_tail && flash_tail_ok(br, dx, dy);
+  p.wfb = p.tail ? ws.take<bf16_t>(dx * dy) : nullptr;
+  p.xtfb = p.tail ? ws.take<bf16_t>(br * dx) : nullptr;
+  p.dttfb = p.tail ? ws.take<bf16_t>(br * dy) : nullptr;
   // backward
   p.dt = ws.take<float>(br * dy);
   if (precision == MI_PREC_F32) p.g = ws.take<float>(br * b);
@@ -145,9 +154,10 @@ static int fast_prep_and_t(const float* x, const float* y, const float* w, const
   if (p.fl.ok) {
     // one launch: T tiles straight from the fp32 operands, the other conversions on the CUs the tiles leave free
     CvtJobs side{};
-    side.j[0] = CvtJob{x, br, dx, nullptr, p.xtb, 0, 0, nullptr};
+    // (with the two-launch tail nobody reads X^T row-major any more: only its fragment-major form)
+    side.j[0] = CvtJob{x, br, dx, nullptr, p.tail ? nullptr : p.xtb, 0, 0, nullptr, 0, 0, p.xtfb};
     side.j[1] = CvtJob{y, b, dy, p.yb, nullptr, 0, 0, p.yfb};
-    side.j[2] = CvtJob{w, dx, dy, p.wb, nullptr, 0, 0, nullptr};
+    side.j[2] = CvtJob{w, dx, dy, p.wb, nullptr, 0, 0, p.wfb};
     side.dup = DupFlagJob{sid_rows, sid_cols, (int)(br / 32), (int)(b / 32), p.fl_dup[0], p.fl_dup[1], row_offset};
     const int rc1 = launch_prep_t(x, w, br, dy, dx, p.tb, p.tfb, side, st, "bilinear prep + T = X W");
     if (rc1 != MI_EINVAL) return rc1;
@@ -155,9 +165,9 @@ static int fast_prep_and_t(const float* x, const float* y, const float* w, const
   const int x3 = p.x3;
   const int ra = x3 == 3 ? 1 : 0, rb = x3 == 3 ? 2 : 0;  // bf16x3 roles of A-side and B-side operands
   CvtJobs jobs{};
-  jobs.j[0] = CvtJob{x, br, dx, p.xb, p.xtb, 0, 0, nullptr, ra, ra};
+  jobs.j[0] = CvtJob{x, br, dx, p.xb, p.xtb, 0, 0, nullptr, ra, ra, p.xtfb};
   jobs.j[1] = CvtJob{y, b, dy, p.yb, p.fl.ok ? nullptr : p.ytb, 0, 0, p.fl.ok ? p.yfb : nullptr, rb, rb};
-  jobs.j[2] = CvtJob{w, dx, dy, p.wb, p.wtb, 0, 0, nullptr, rb, rb};
+  jobs.j[2] = CvtJob{w, dx, dy, p.wb, p.wtb, 0, 0, p.wfb, rb, rb};
   if (p.fl.ok) jobs.dup = DupFlagJob{sid_rows, sid_cols, (int)(br / 32), (int)(b / 32), p.fl_dup[0], p.fl_dup[1], row_offset};
   int rc = launch_cvt_transpose3(jobs, st, "bilinear prep X Y W");
   if (rc) return rc;
@@ -183,6 +193,44 @@ static int flash_stage(const int64_t* sid_rows, const int64_t* sid_cols, int64_t
   a.n_problems = grad ? 2 : 1;
   a.slab_f16 = p.fl.slab_f16 ? 1 : 0;
   return launch_flash(a, dy, grad, st, grad ? "bilinear fused S | P Y | P^T T" : "bilinear fused S + LSE");
+}
+
+// The backward's tail in two launches (mi_bilinear_tail.h): [partial sums -> dT rows, grad_y; dX = dT W^T; dT^T
+// fragment-major] and [dW = X^T dT].  `merge` != null: the first launch also merges the fused kernel's records into the
+// statistics and the loss (the one-call step: no finalize launch).
+struct TailMerge {
+  int estimator;
+  float* loss_out;
+  mi_stats* stats_out;
+  float* partials_out;
+};
+static int bilinear_tail(int64_t br, int64_t b, int64_t row_offset, int64_t dx, int64_t dy, const mi_stats* stats,
+                         const float* grad_out, float* grad_x, float* grad_y, float* grad_w, const BilinearPlan& p,
+                         const TailMerge* merge, hipStream_t st) {
+  FlashTailArgs ta{};
+  ta.j[0] = FlashReduceJob{p.fl_slab[0], p.fl_rec[0], p.fl.n_split[0], p.fl.n_rb[0], br, p.yb, b, row_offset,
+                           nullptr, nullptr, nullptr};
+  ta.j[1] = FlashReduceJob{p.fl_slab[1], p.fl_rec[1], p.fl.n_split[1], p.fl.n_rb[1], b, p.tb, br, -row_offset,
+                           grad_y, nullptr, nullptr};
+  ta.stats = stats;
+  ta.grad_out = grad_out;
+  if (merge) {
+    ta.merge_rec = p.fl_rec[0];
+    ta.n_merge = p.fl.n_rec[0];
+    ta.n_pos = b;
+    ta.estimator = merge->estimator;
+    ta.loss_out = merge->loss_out;
+    ta.stats_out = merge->stats_out;
+    ta.partials_out = merge->partials_out;
+  }
+  ta.w_frag = p.wfb;
+  ta.dx = dx;
+  ta.grad_x = grad_x;
+  ta.dtt_frag = p.dttfb;
+  int rc = launch_flash_tail(ta, dy, p.fl.slab_f16, merge != nullptr, st,
+                             merge ? "bilinear sums -> loss, dT, dY | dX = dT W^T" : "bilinear sums -> dT, dY | dX = dT W^T");
+  if (rc) return rc;
+  return launch_bilinear_dw(DwArgs{p.xtfb, p.dttfb, dx, dy, br, grad_w}, st, "bilinear dW = X^T dT");
 }
 
 static int bilinear_fwd_fast(const float* x, const float* y, const float* w, const int64_t* sid_rows,
@@ -215,6 +263,7 @@ static int bilinear_bwd_fast(const int64_t* sid_rows, const int64_t* sid_cols, i
                              int64_t dx, int64_t dy, const mi_stats* stats, const float* grad_out, float* grad_x,
                              float* grad_y, float* grad_w, const BilinearPlan& p, bool flash_sums, hipStream_t st) {
   int rc = MI_OK;
+  if (flash_sums && p.tail) return bilinear_tail(br, b, row_offset, dx, dy, stats, grad_out, grad_x, grad_y, grad_w, p, nullptr, st);
   if (flash_sums) {
     // the forward's fused launch left U, V as slabs: scale by exp(m_ref - lse), subtract the diagonal term, add the
     // slabs in a fixed order -> dT (bf16, both orientations, operands of dW | dX) and grad_y
@@ -559,6 +608,43 @@ int mi_bilinear_bwd(const float* x, const float* y, const float* w, const int64_
                                              grad_out, grad_x, grad_y, grad_w, p, st);
   return bilinear_bwd_impl<float, float>(x, y, w, sid_rows, sid_cols, b_rows, b, row_offset, d_img, d_txt, stats,
                                          grad_out, grad_x, grad_y, grad_w, p, st);
+}
+
+/* One critic step -- forward, loss and every gradient -- in one call (single GPU: b_rows == b).  Where the fused kernels
+ * take the shape this is four launches: conversions + T, the fused B x B kernel, [records -> statistics and loss; partial
+ * sums -> dT, grad_y; dX], dW.  Nothing needs the loss between the fused kernel and the gradients, so the statistics are
+ * merged inside the third launch (no finalize launch).  Other shapes / precisions: the forward and the backward entry
+ * points, one after the other.  grad_out may be NULL (dL/dloss = 1). */
+int mi_bilinear_step(const float* x, const float* y, const float* w, const int64_t* sid, int64_t b, int64_t d_img,
+                     int64_t d_txt, int estimator, int precision, const float* grad_out, float* loss_out, mi_stats* stats,
+                     float* partials_out, float* grad_x, float* grad_y, float* grad_w, void* workspace,
+                     size_t workspace_bytes, void* stream) {
+  MI_CHECK_ARG(x && y && sid && stats && grad_x && grad_y && workspace, "mi_bilinear_step: null pointer");
+  MI_CHECK_ARG((w && grad_w) || (!w && d_img == d_txt),
+               "mi_bilinear_step: w == NULL (separable form) needs d_img == d_txt; w != NULL needs grad_w");
+  int rc = check_common("mi_bilinear_step", b, b, 0, d_img, d_txt, precision);
+  if (rc) return rc;
+  MI_CHECK_ARG(estimator == MI_DV || estimator == MI_INFONCE, "mi_bilinear_step: unknown estimator %d", estimator);
+  Workspace ws(workspace, workspace_bytes);
+  BilinearPlan p = plan_bilinear(ws, b, b, d_img, d_txt, precision);
+  if (!ws.ok()) {
+    set_error("mi_bilinear_step: workspace too small (%zu < %zu)", workspace_bytes, ws.off);
+    return MI_EWORKSPACE;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  if (fast_ok(b, b, d_img, d_txt, precision, w != nullptr) && p.fl.ok && p.tail) {
+    rc = fast_prep_and_t(x, y, w, sid, sid, b, b, 0, d_img, d_txt, p, st);
+    if (rc) return rc;
+    rc = flash_stage(sid, sid, b, b, 0, d_txt, true, p, st);
+    if (rc) return rc;
+    const TailMerge m{estimator, loss_out, stats, partials_out};
+    return bilinear_tail(b, b, 0, d_img, d_txt, stats, grad_out, grad_x, grad_y, grad_w, p, &m, st);
+  }
+  rc = mi_bilinear_fwd(x, y, w, sid, sid, b, b, 0, d_img, d_txt, estimator, precision, 1, loss_out, stats, partials_out,
+                       nullptr, workspace, workspace_bytes, stream);
+  if (rc) return rc;
+  return mi_bilinear_bwd(x, y, w, sid, sid, b, b, 0, d_img, d_txt, precision, stats, grad_out, grad_x, grad_y, grad_w,
+                         workspace, workspace_bytes, 1, stream);
 }
 
 }  // extern "C"

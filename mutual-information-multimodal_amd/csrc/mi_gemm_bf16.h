@@ -1405,6 +1405,7 @@ struct CvtJob {
   bf16_t* out_frag;     // fragment-major copy (see EpiOut::bf_frag; R % 32 == 0, C % 16 == 0) or null
   int split_rm;         // bf16x3 mode (split3_offsets): out_rm is [R][3 C] holding hi and lo parts; 0: plain bf16
   int split_t;          // same for out_t, [C][3 R]
+  bf16_t* out_t_frag;   // fragment-major copy of the TRANSPOSE [C][R] (C % 32 == 0, R % 16 == 0) or null
 };
 // equal-id flags of the fused bilinear kernel, computed by spare workgroups of the conversion launch (blockIdx.z == 3)
 struct DupFlagJob {
@@ -1495,7 +1496,7 @@ __device__ __forceinline__ void cvt_tile_block(const CvtJob& J, int bx, int by, 
       if (J.out_frag) *reinterpret_cast<bf16x4*>(J.out_frag + frag_major_offset(r, c & ~(int64_t)7, J.C) + (c & 4)) = o;
     }
   }
-  if (!J.out_t) return;
+  if (!J.out_t && !J.out_t_frag) return;
   __syncthreads();
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
@@ -1504,7 +1505,9 @@ __device__ __forceinline__ void cvt_tile_block(const CvtJob& J, int bx, int by, 
     if (c < J.C && r < J.R) {
       const bf16x4 o = {(bf16_t)tile[4 * tx][cl], (bf16_t)tile[4 * tx + 1][cl], (bf16_t)tile[4 * tx + 2][cl],
                         (bf16_t)tile[4 * tx + 3][cl]};
-      if (!J.split_t) {
+      if (J.out_t_frag) *reinterpret_cast<bf16x4*>(J.out_t_frag + frag_major_offset(c, r & ~(int64_t)7, J.R) + (r & 4)) = o;
+      if (!J.out_t) {
+      } else if (!J.split_t) {
         *reinterpret_cast<bf16x4*>(J.out_t + c * J.R + r) = o;
       } else {
         int64_t h0, h1, lo;
@@ -1565,9 +1568,11 @@ static inline int launch_cvt_transpose3(const CvtJobs& jobs, hipStream_t st, con
     if (J.R > rmax) rmax = J.R;
     if (J.C > cmax) cmax = J.C;
     vec = vec && J.R % 4 == 0 && J.C % 4 == 0 && (uintptr_t)J.in % 16 == 0 && (uintptr_t)J.out_rm % 8 == 0 &&
-          (uintptr_t)J.out_t % 8 == 0 && J.slab_stride % 4 == 0 && (!J.out_frag || (J.R % 32 == 0 && J.C % 16 == 0));
+          (uintptr_t)J.out_t % 8 == 0 && J.slab_stride % 4 == 0 && (!J.out_frag || (J.R % 32 == 0 && J.C % 16 == 0)) &&
+          (!J.out_t_frag || (J.C % 32 == 0 && J.R % 16 == 0));
   }
-  if (!vec && (jobs.dup.na > 0 || jobs.j[0].out_frag || jobs.j[1].out_frag || jobs.j[2].out_frag || jobs.j[3].out_frag)) {
+  if (!vec && (jobs.dup.na > 0 || jobs.j[0].out_frag || jobs.j[1].out_frag || jobs.j[2].out_frag || jobs.j[3].out_frag ||
+               jobs.j[0].out_t_frag || jobs.j[1].out_t_frag || jobs.j[2].out_t_frag || jobs.j[3].out_t_frag)) {
     set_error("%s: fragment-major outputs / id flags need the vectorised conversion kernel (aligned, multiples of 4)", what);
     return MI_ESHAPE;
   }
@@ -1743,7 +1748,8 @@ static inline int launch_prep_t(const float* x, const float* w, int64_t m, int64
   for (int q = 0; q < 4; ++q) {
     const CvtJob& J = jobs.j[q];
     if (J.R > 0 && (J.R % 4 != 0 || J.C % 4 != 0 || (uintptr_t)J.in % 16 != 0 || (uintptr_t)J.out_rm % 8 != 0 ||
-                    (uintptr_t)J.out_t % 8 != 0 || J.n_slab > 1 || (J.out_frag && (J.R % 32 != 0 || J.C % 16 != 0))))
+                    (uintptr_t)J.out_t % 8 != 0 || J.n_slab > 1 || (J.out_frag && (J.R % 32 != 0 || J.C % 16 != 0)) ||
+                    (J.out_t_frag && (J.C % 32 != 0 || J.R % 16 != 0))))
       return MI_EINVAL;
     a.job_begin[q] = total;
     a.job_nx[q] = J.R > 0 ? (int)((J.C + 63) / 64) : 1;

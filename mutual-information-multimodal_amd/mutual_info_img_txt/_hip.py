@@ -45,6 +45,7 @@ SIGNATURES = {
     "mi_bilinear_workspace_bytes": (_SZ, [_I64, _I64, _I64, _I64, _I]),
     "mi_bilinear_fwd": (c_int, [_P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I, _I, _I, _P, _P, _P, _P, _P, _SZ, _P]),
     "mi_bilinear_bwd": (c_int, [_P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I, _P, _P, _P, _P, _P, _P, _SZ, _I, _P]),
+    "mi_bilinear_step": (c_int, [_P, _P, _P, _P, _I64, _I64, _I64, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _SZ, _P]),
     "mi_separable_workspace_bytes": (_SZ, [_I64, _I64, _I64, _I64, _I64, _I]),
     "mi_separable_fwd": (c_int, [_P] * 6 + [_I64] * 6 + [_I, _I, _I] + [_P] * 4 + [_SZ, _P]),
     "mi_separable_bwd": (c_int, [_P] * 6 + [_I64] * 6 + [_I] + [_P] * 7 + [_SZ, _I, _P]),

@@ -121,6 +121,19 @@ class GraphedMiStep:
                       self.grad_x.data_ptr(), self.grad_y.data_ptr(), *[t.data_ptr() for t in g], self.ws.data_ptr(),
                       self.ws.numel())
 
+    def _step(self):
+        """Forward + backward as ONE C-ABI call where the library has one (bilinear critic: mi_bilinear_step, four launches
+        and no finalize kernel); the two calls otherwise."""
+        p, g = self.params, self.grad_params
+        if self.kind == "bilinear":
+            _hip.call("mi_bilinear_step", self.device, self.x.data_ptr(), self.y.data_ptr(), p[0].data_ptr() if p else None,
+                      self.sid.data_ptr(), self.b, self.dx, self.dy, self.est, self.prec, self.grad_out.data_ptr(),
+                      self.loss_buf.data_ptr(), self.stats.data_ptr(), self.record.data_ptr(), self.grad_x.data_ptr(),
+                      self.grad_y.data_ptr(), g[0].data_ptr() if g else None, self.ws.data_ptr(), self.ws.numel())
+        else:
+            self._fwd()
+            self._bwd()
+
     def _capture(self):
         # warm-up on a side stream: module loading and the one-time kernel-attribute calls must not fall into a capture
         side = torch.cuda.Stream(device=self.device)
@@ -129,6 +142,7 @@ class GraphedMiStep:
             for _ in range(2):
                 self._fwd()
                 self._bwd()
+                self._step()
         torch.cuda.current_stream(self.device).wait_stream(side)
         torch.cuda.synchronize(self.device)
         # thread_local: another thread's allocator traffic (a DataLoader's pin-memory thread) must not invalidate a capture
@@ -142,8 +156,7 @@ class GraphedMiStep:
         # short backward
         self.graph_step = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph_step, pool=self.graph_fwd.pool(), capture_error_mode="thread_local"):
-            self._fwd()
-            self._bwd()
+            self._step()
 
     # ------------------------------------------------------------------------------------------ replay
     def forward(self) -> torch.Tensor:
@@ -168,15 +181,13 @@ class GraphedMiStep:
         if self.graph_step is not None:
             self.graph_step.replay()
         else:
-            self._fwd()
-            self._bwd()
+            self._step()
         return self.loss_buf
 
     def step_eager(self) -> torch.Tensor:
         """The same C-ABI calls issued one by one (no replay overhead; needs a host that keeps ahead of ~10 us kernels)."""
         self.generation += 1
-        self._fwd()
-        self._bwd()
+        self._step()
         return self.loss_buf
 
     def set_inputs(self, embedding_img: torch.Tensor, embedding_txt: torch.Tensor, study_id=None) -> None:

@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol(lib):
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/mi_critic.h but not exported"
     assert sorted(_hip.SIGNATURES) == declared, "ctypes signature table out of sync with the header"
-    assert lib.mi_abi_version() == 2
+    assert lib.mi_abi_version() == 3
 
 
 def test_workspace_queries_are_host_only(lib):

@@ -236,3 +236,51 @@ def test_flash_small_batches_d512(dev, b):
         loss_fwd = mi_critics.fused_mi_bound(x.to(dev), y.to(dev), sid, _critic(dev, w), "dv", precision="bf16")
     # same scores, same masks; the two kernels keep their own reference points, so the sums differ in rounding only
     assert abs(float(loss_fwd.sum()) - float(loss.sum())) < 1e-4 * max(abs(float(loss.sum())), 1.0)
+
+
+@pytest.mark.parametrize("b,dx,dy,est,dup", [(1024, 512, 512, "infonce", True), (4096, 512, 512, "dv", False),
+                                            (512, 256, 128, "dv", True), (256, 64, 256, "infonce", False),
+                                            (96, 128, 128, "dv", True)])
+def test_one_call_step_equals_the_two_calls(dev, b, dx, dy, est, dup):
+    """mi_bilinear_step (one C-ABI call: the statistics are merged by the launch that also produces dT / grad_y / grad_x,
+    no finalize launch) against mi_bilinear_fwd + mi_bilinear_bwd on the same inputs: the same kernels and the same
+    merge order, so loss, statistics and every gradient must agree BIT FOR BIT; and against the rounded oracle at the
+    stated bf16 tolerances.  (b = 96: a shape the two-launch tail does not take -- the step then runs the two calls.)"""
+    from mutual_info_img_txt import _hip
+    lib = _hip.load()
+    gen = torch.Generator().manual_seed(b + 7 * dx)
+    x = torch.randn(b, dx, generator=gen)
+    y = torch.randn(b, dy, generator=gen)
+    w = torch.randn(dx, dy, generator=gen) * (0.25 / math.sqrt(dx))
+    sid = torch.arange(b)
+    if dup:
+        for n in range(max(b // 8, 4)):
+            sid[n] = n - (n % 2)
+        sid[b - 3] = sid[b // 3]
+    xd, yd, wd, sd = x.to(dev), y.to(dev), w.to(dev), sid.to(dev)
+    code, prec = _hip.ESTIMATORS[est], _hip.MI_PREC_BF16
+    nbytes = lib.mi_bilinear_workspace_bytes(b, b, dx, dy, prec)
+    go = torch.full((1,), 0.75, device=dev)
+
+    def outputs():
+        return (torch.zeros(1, device=dev), _hip.new_stats(dev), torch.zeros(_hip.RECORD_FLOATS, device=dev),
+                torch.zeros_like(xd), torch.zeros_like(yd), torch.zeros_like(wd), _hip.workspace(nbytes, dev))
+    l1, s1, r1, gx1, gy1, gw1, ws1 = outputs()
+    _hip.call("mi_bilinear_step", dev, xd.data_ptr(), yd.data_ptr(), wd.data_ptr(), sd.data_ptr(), b, dx, dy, code, prec,
+              go.data_ptr(), l1.data_ptr(), s1.data_ptr(), r1.data_ptr(), gx1.data_ptr(), gy1.data_ptr(), gw1.data_ptr(),
+              ws1.data_ptr(), ws1.numel())
+    l2, s2, r2, gx2, gy2, gw2, ws2 = outputs()
+    _hip.call("mi_bilinear_fwd", dev, xd.data_ptr(), yd.data_ptr(), wd.data_ptr(), sd.data_ptr(), sd.data_ptr(), b, b, 0, dx, dy,
+              code, prec, 1, l2.data_ptr(), s2.data_ptr(), r2.data_ptr(), None, ws2.data_ptr(), ws2.numel())
+    _hip.call("mi_bilinear_bwd", dev, xd.data_ptr(), yd.data_ptr(), wd.data_ptr(), sd.data_ptr(), sd.data_ptr(), b, b, 0, dx, dy,
+              prec, s2.data_ptr(), go.data_ptr(), gx2.data_ptr(), gy2.data_ptr(), gw2.data_ptr(), ws2.data_ptr(), ws2.numel(), 1)
+    torch.cuda.synchronize()
+    assert torch.equal(l1, l2) and torch.equal(s1, s2) and torch.equal(r1, r2)
+    assert torch.equal(gx1, gx2) and torch.equal(gy1, gy2) and torch.equal(gw1, gw2)
+    o = orc.bilinear_step_rounded(x, y, w, sid, est)
+    sc = float(o["scores"].abs().max())
+    assert abs(float(l1) - float(o["loss"].sum())) < 2e-3 * max(sc, 1.0)
+    assert _hip.stats_dict(s1)["n_neg"] == int(orc.negative_mask(sid).sum())
+    for name, got, ref in (("dx", gx1, o["dx"]), ("dy", gy1, o["dy"]), ("dw", gw1, o["dw"])):
+        err = _rel(got.cpu() / 0.75, ref)
+        assert err < 1e-2, (name, err)
