@@ -225,7 +225,8 @@ static int bilinear_tail(int64_t br, int64_t b, int64_t row_offset, int64_t dx, 
   }
   ta.w_frag = p.wfb;
   ta.dx = dx;
-  ta.grad_x = grad_x;
+  static const bool diag_no_dx = getenv("MI_TAIL_DIAG_NO_DX") != nullptr;  // timing experiment (wrong grad_x / grad_w)
+  ta.grad_x = diag_no_dx ? nullptr : grad_x;
   ta.dtt_frag = p.dttfb;
   int rc = launch_flash_tail(ta, dy, p.fl.slab_f16, merge != nullptr, st,
                              merge ? "bilinear sums -> loss, dT, dY | dX = dT W^T" : "bilinear sums -> dT, dY | dX = dT W^T");

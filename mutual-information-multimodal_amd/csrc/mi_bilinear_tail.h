@@ -82,6 +82,25 @@ __global__ __launch_bounds__(kTailThreads, 2) void flash_tail_kernel(FlashTailAr
       }
     }
 
+  // ... and so does everything else this workgroup reads that does not depend on the statistics: the splits' reference
+  // points and scales, and the rows subtracted on the diagonal.  (A block moves ~200 KB; what it costs is the chain of
+  // DEPENDENT round trips to memory, each 1 - 2 us under load.)
+  float m_rec[4], u_rec[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    m_rec[q] = J.rec[wvs[q]].m;
+    u_rec[q] = F16 ? unscale[wvs[q]] : 1.0f;
+  }
+  const int orow = tid >> 4;  // row-major pass below: 16 threads per row, each D / 128 groups of 8 columns
+  const int64_t ojo = i0 + orow + J.diag;
+  const bool has_other = ojo >= 0 && ojo < J.n_other;
+  bf16x8 oth[D / 128];
+#pragma unroll
+  for (int g = 0; g < D / 128; ++g) {
+    oth[g] = bf16x8{};
+    if (has_other) oth[g] = *reinterpret_cast<const bf16x8*>(J.other + ojo * D + ((tid & 15) + 16 * g) * 8);
+  }
+
   // ---- statistics
   float lse, n_pos_f;
   if constexpr (MERGE) {
@@ -156,8 +175,11 @@ __global__ __launch_bounds__(kTailThreads, 2) void flash_tail_kernel(FlashTailAr
     for (int q = 0; q < 4; ++q) {
       const int s = s0 + q < J.n_split ? s0 + q : J.n_split - 1;
       wvs[q] = ((int64_t)s * J.n_rb + rb) * 4 + w;
-      const float m = J.rec[wvs[q]].m;
-      cs[q] = (s0 + q < J.n_split && m > MI_NEG_INF) ? go * __expf(m - lse) * (F16 ? unscale[wvs[q]] : 1.0f) : 0.0f;
+      if (s0 > 0) {
+        m_rec[q] = J.rec[wvs[q]].m;
+        u_rec[q] = F16 ? unscale[wvs[q]] : 1.0f;
+      }
+      cs[q] = (s0 + q < J.n_split && m_rec[q] > MI_NEG_INF) ? go * __expf(m_rec[q] - lse) * u_rec[q] : 0.0f;
     }
     if (s0 > 0) {  // (more than four splits: the next round's loads)
 #pragma unroll
@@ -229,9 +251,8 @@ __global__ __launch_bounds__(kTailThreads, 2) void flash_tail_kernel(FlashTailAr
 
   // ---- row-major pass: subtract the diagonal term; grad_y (job 1) goes out here
   {
-    const int row = tid >> 4;  // 16 threads per row, each D / 128 groups of 8 columns
-    const int64_t i = i0 + row, ojo = i + J.diag;
-    const bool has_other = ojo >= 0 && ojo < J.n_other;
+    const int row = orow;
+    const int64_t i = i0 + row;
 #pragma unroll
     for (int g = 0; g < D / 128; ++g) {
       const int c = ((tid & 15) + 16 * g) * 8;
@@ -239,7 +260,7 @@ __global__ __launch_bounds__(kTailThreads, 2) void flash_tail_kernel(FlashTailAr
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] = tile[row][c + e];
       if (has_other) {
-        const bf16x8 o = *reinterpret_cast<const bf16x8*>(J.other + ojo * D + c);
+        const bf16x8 o = oth[g];
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] -= gpos * (float)o[e];
         if (job == 0) {
