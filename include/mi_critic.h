@@ -150,6 +150,14 @@ int mi_bilinear_bwd(const float* x, const float* y, const float* w, const int64_
                     float* grad_y, float* grad_w, void* workspace, size_t workspace_bytes,
                     int workspace_from_forward, void* stream);
 
+/* fp8 mode (MI_PREC_FP8) on a sharded batch: the per-tensor scales must be the whole batch's.  The forward's preparation
+ * in three stages around the caller's two MAX all-reduces of amax_io (4 floats on the device: x, y, w, T):
+ *   stage 0 -> amax_io[0..2] | all-reduce MAX | stage 1 -> amax_io[3] | all-reduce MAX | stage 2,
+ * then mi_bilinear_fwd(..., need_grad | 2, ...) on the SAME workspace (bit 1 of need_grad: the fp8 operands are staged)
+ * and mi_bilinear_bwd(..., workspace_from_forward = 1).  BASELINE.json configs[4] (fp8, 8 GPUs). */
+int mi_bilinear_fp8_stage(const float* x, const float* y, const float* w, int64_t b_rows, int64_t b, int64_t d_img,
+                          int64_t d_txt, int stage, float* amax_io, void* workspace, size_t workspace_bytes, void* stream);
+
 /* One critic step in ONE call (single GPU; the sharded case needs the cross-rank merge between the forward and the
  * backward and uses the two calls above): forward, statistics, loss and every gradient of  grad_out[0] * loss
  * (grad_out == NULL: 1).  Same inputs, outputs and workspace as mi_bilinear_fwd + mi_bilinear_bwd with b_rows == b,

@@ -355,13 +355,14 @@ static int bilinear_bwd_small(int64_t br, int64_t dx, int64_t dy, float* grad_x,
 }
 
 // ------------------------------------------------------------------------------------------------ fp8 path (mi_fp8.h)
-// absmax -> scales -> e4m3 operands; T on the fp8 MFMA with its absmax in the epilogue; T quantised
-static int fp8_prep_and_t(const float* x, const float* y, const float* w, int64_t br, int64_t b, int64_t dx, int64_t dy,
-                          const BilinearPlan& p, hipStream_t st) {
-  {
-    const hipError_t e = hipMemsetAsync(p.f8sc, 0, sizeof(Fp8Scales), st);
-    if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync(fp8 scales)");
-  }
+// absmax -> scales -> e4m3 operands; T on the fp8 MFMA with its absmax in the epilogue; T quantised.  Three stages, so
+// that a sharded run can make the scales GLOBAL between them (mi_bilinear_fp8_stage): the absmax of the local image rows
+// and of the local rows of T differ between ranks; a MAX all-reduce of the four numbers makes every rank quantise with
+// the scales a single GPU would have used.
+static int fp8_stage0(const float* x, const float* y, const float* w, int64_t br, int64_t b, int64_t dx, int64_t dy,
+                      const BilinearPlan& p, hipStream_t st) {
+  const hipError_t e = hipMemsetAsync(p.f8sc, 0, sizeof(Fp8Scales), st);
+  if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync(fp8 scales)");
   AbsmaxJobs aj{};
   aj.in[0] = x; aj.n[0] = br * dx; aj.slot[0] = 0;
   aj.in[1] = y; aj.n[1] = b * dy; aj.slot[1] = 1;
@@ -372,6 +373,10 @@ static int fp8_prep_and_t(const float* x, const float* y, const float* w, int64_
     hipLaunchKernelGGL(fp8_absmax_kernel, dim3(kAbsmaxBlocks, 3), dim3(256), 0, st, aj);
   }
   MI_LAUNCH_CHECK("fp8_absmax_kernel");
+  return MI_OK;
+}
+static int fp8_stage1(const float* x, const float* y, const float* w, int64_t br, int64_t b, int64_t dx, int64_t dy,
+                      const BilinearPlan& p, hipStream_t st) {
   QuantJobs qj{};
   qj.j[0] = QuantJob{x, br, dx, 0, p.qx8, nullptr, nullptr, p.xtb};   // A of T = X W; X^T (bf16) for dW
   qj.j[1] = QuantJob{y, b, dy, 1, p.qy8, nullptr, nullptr, p.ytb};    // B of S = T Y^T; Y^T (bf16) for dT
@@ -385,8 +390,9 @@ static int fp8_prep_and_t(const float* x, const float* y, const float* w, int64_
                        0, st, qj);
   }
   MI_LAUNCH_CHECK("fp8_quantize_kernel");
-  int rc = launch_gemm_fp8(GemmF8Args{p.qx8, dx, p.qwt8, dx, br, dy, dx}, EpiT8{p.t, p.f8sc}, st, "fp8 T = X W");
-  if (rc) return rc;
+  return launch_gemm_fp8(GemmF8Args{p.qx8, dx, p.qwt8, dx, br, dy, dx}, EpiT8{p.t, p.f8sc}, st, "fp8 T = X W");
+}
+static int fp8_stage2(int64_t br, int64_t dy, const BilinearPlan& p, hipStream_t st) {
   QuantJobs qt{};
   qt.j[0] = QuantJob{p.t, br, dy, 3, p.qt8, nullptr, nullptr, p.ttb};  // A of S; T^T (bf16) for dY
   qt.sc = p.f8sc;
@@ -398,12 +404,20 @@ static int fp8_prep_and_t(const float* x, const float* y, const float* w, int64_
   MI_LAUNCH_CHECK("fp8_quantize_kernel");
   return MI_OK;
 }
+static int fp8_prep_and_t(const float* x, const float* y, const float* w, int64_t br, int64_t b, int64_t dx, int64_t dy,
+                          const BilinearPlan& p, hipStream_t st) {
+  int rc = fp8_stage0(x, y, w, br, b, dx, dy, p, st);
+  if (rc) return rc;
+  rc = fp8_stage1(x, y, w, br, b, dx, dy, p, st);
+  if (rc) return rc;
+  return fp8_stage2(br, dy, p, st);
+}
 
 static int bilinear_fwd_fp8(const float* x, const float* y, const float* w, const int64_t* sid_rows, const int64_t* sid_cols,
                             int64_t br, int64_t b, int64_t row_offset, int64_t dx, int64_t dy, int estimator,
                             float* loss_out, mi_stats* stats, float* partials_out, float* scores_out,
-                            const BilinearPlan& p, hipStream_t st) {
-  int rc = fp8_prep_and_t(x, y, w, br, b, dx, dy, p, st);
+                            const BilinearPlan& p, bool staged, hipStream_t st) {
+  int rc = staged ? MI_OK : fp8_prep_and_t(x, y, w, br, b, dx, dy, p, st);  // staged: mi_bilinear_fp8_stage made them
   if (rc) return rc;
   EpiScaled<EpiScoreLse2> e{EpiScoreLse2{sid_rows, sid_cols, row_offset, scores_out, p.partials},
                             {&p.f8sc->scale[3], nullptr}, {&p.f8sc->scale[1], nullptr}};
@@ -550,7 +564,7 @@ int mi_bilinear_fwd(const float* x, const float* y, const float* w, const int64_
       return MI_ESHAPE;
     }
     return bilinear_fwd_fp8(x, y, w, sid_rows, sid_cols, b_rows, b, row_offset, d_img, d_txt, estimator, loss_out, stats,
-                            partials_out, scores_out, p, st);
+                            partials_out, scores_out, p, (need_grad & 2) != 0, st);
   }
   if (fast_ok(b_rows, b, d_img, d_txt, precision, w != nullptr))
     return bilinear_fwd_fast(x, y, w, sid_rows, sid_cols, b_rows, b, row_offset, d_img, d_txt, estimator, need_grad,
@@ -609,6 +623,51 @@ int mi_bilinear_bwd(const float* x, const float* y, const float* w, const int64_
                                              grad_out, grad_x, grad_y, grad_w, p, st);
   return bilinear_bwd_impl<float, float>(x, y, w, sid_rows, sid_cols, b_rows, b, row_offset, d_img, d_txt, stats,
                                          grad_out, grad_x, grad_y, grad_w, p, st);
+}
+
+/* fp8 mode on a SHARDED batch: the per-tensor scales must be those of the whole batch.  The forward's preparation in
+ * three stages around the caller's two MAX all-reduces of amax_io (4 floats, device):
+ *   stage 0: local absmax of x (slot 0), y (1), w (2) -> amax_io[0..2]                    | all-reduce MAX amax_io
+ *   stage 1: quantise x, y, w with amax_io[0..2]; T = x_q W_q; local absmax of T -> amax_io[3] | all-reduce MAX amax_io
+ *   stage 2: quantise T with amax_io[3]
+ * then mi_bilinear_fwd(..., need_grad | 2, ...) on the same workspace (bit 1: "the fp8 operands are staged"). */
+int mi_bilinear_fp8_stage(const float* x, const float* y, const float* w, int64_t b_rows, int64_t b, int64_t d_img,
+                          int64_t d_txt, int stage, float* amax_io, void* workspace, size_t workspace_bytes, void* stream) {
+  MI_CHECK_ARG(x && y && w && amax_io && workspace, "mi_bilinear_fp8_stage: null pointer");
+  MI_CHECK_ARG(stage >= 0 && stage <= 2, "mi_bilinear_fp8_stage: stage %d outside 0..2", stage);
+  int rc = check_common("mi_bilinear_fp8_stage", b_rows, b, 0, d_img, d_txt, MI_PREC_FP8);
+  if (rc) return rc;
+  if (!fp8_ok(b_rows, b, d_img, d_txt, MI_PREC_FP8, true)) {
+    set_error("mi_bilinear_fp8_stage: the fp8 mode needs batch sizes that are multiples of 8 and widths that are multiples of 16");
+    return MI_ESHAPE;
+  }
+  Workspace ws(workspace, workspace_bytes);
+  BilinearPlan p = plan_bilinear(ws, b_rows, b, d_img, d_txt, MI_PREC_FP8);
+  if (!ws.ok()) {
+    set_error("mi_bilinear_fp8_stage: workspace too small (%zu < %zu)", workspace_bytes, ws.off);
+    return MI_EWORKSPACE;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  // non-negative floats and their bit patterns order alike: the absmax slots hold bit patterns, amax_io floats
+  auto copy = [&](void* dst, const void* src, size_t n) {
+    const hipError_t e = hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToDevice, st);
+    return e == hipSuccess ? MI_OK : hip_fail(e, "hipMemcpyAsync(fp8 absmax)");
+  };
+  if (stage == 0) {
+    rc = fp8_stage0(x, y, w, b_rows, b, d_img, d_txt, p, st);
+    if (rc) return rc;
+    return copy(amax_io, p.f8sc->amax_bits, 3 * sizeof(float));
+  }
+  if (stage == 1) {
+    rc = copy(p.f8sc->amax_bits, amax_io, 3 * sizeof(float));
+    if (rc) return rc;
+    rc = fp8_stage1(x, y, w, b_rows, b, d_img, d_txt, p, st);
+    if (rc) return rc;
+    return copy(amax_io + 3, &p.f8sc->amax_bits[3], sizeof(float));
+  }
+  rc = copy(&p.f8sc->amax_bits[3], amax_io + 3, sizeof(float));
+  if (rc) return rc;
+  return fp8_stage2(b_rows, d_txt, p, st);
 }
 
 /* One critic step -- forward, loss and every gradient -- in one call (single GPU: b_rows == b).  Where the fused kernels

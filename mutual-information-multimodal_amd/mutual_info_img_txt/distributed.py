@@ -30,19 +30,40 @@ class HipBilinearOps:
     """S = (X W) Y^T row block; params = [W]."""
     n_params = 1
 
+    def __init__(self):
+        self._fp8_ws = None  # workspace of a staged fp8 preparation, handed on to forward()
+
+    def fp8_stage(self, stage, x, y_all, params, amax):
+        """One stage of the fp8 mode's preparation (mi_bilinear_fp8_stage): ``amax`` (4 floats on the device: x, y, W, T)
+        is MAX-all-reduced by the caller between the stages, so that every rank quantises with the whole batch's scales."""
+        lib = _hip.load()
+        (w,) = params
+        br, dx = x.shape
+        b, dy = y_all.shape
+        if stage == 0:
+            self._fp8_ws = _hip.workspace(lib.mi_bilinear_workspace_bytes(br, b, dx, dy, _hip.MI_PREC_FP8), x.device)
+        ws = self._fp8_ws
+        _hip.call("mi_bilinear_fp8_stage", x.device, x.data_ptr(), y_all.data_ptr(), w.data_ptr(), br, b, dx, dy, int(stage),
+                  amax.data_ptr(), ws.data_ptr(), ws.numel())
+
     def forward(self, x, y_all, params, sid_rows, sid_all, row_offset, estimator, precision, need_grad):
         lib = _hip.load()
         (w,) = params
         br, dx = x.shape
         b, dy = y_all.shape
         dev = x.device
-        ws = _hip.workspace(lib.mi_bilinear_workspace_bytes(br, b, dx, dy, precision), dev)
+        staged = precision == _hip.MI_PREC_FP8 and self._fp8_ws is not None
+        if staged:
+            ws, self._fp8_ws = self._fp8_ws, None
+            need_grad = int(bool(need_grad)) | 2  # bit 1: the fp8 operands are staged in this workspace
+        else:
+            ws = _hip.workspace(lib.mi_bilinear_workspace_bytes(br, b, dx, dy, precision), dev)
         stats = _hip.new_stats(dev)
         loss = torch.empty(1, dtype=torch.float32, device=dev)
         record = torch.empty(_hip.RECORD_FLOATS, dtype=torch.float32, device=dev)
         _hip.call("mi_bilinear_fwd", dev, x.data_ptr(), y_all.data_ptr(), w.data_ptr(), sid_rows.data_ptr(),
                                        sid_all.data_ptr(), br, b, row_offset, dx, dy, estimator, precision,
-                                       int(bool(need_grad)), loss.data_ptr(), stats.data_ptr(), record.data_ptr(), None,
+                                       int(need_grad), loss.data_ptr(), stats.data_ptr(), record.data_ptr(), None,
                                        ws.data_ptr(),
                                        ws.numel())
         return record, (x, y_all, w, sid_rows, sid_all, row_offset, precision, ws)
@@ -140,6 +161,19 @@ def _reduce_scatter_rows(t: torch.Tensor, group) -> torch.Tensor:
     return out
 
 
+def fp8_global_scales(ops, x, y_all, params, group) -> None:
+    """fp8 mode (BASELINE configs[4]) on a sharded batch: per-tensor scales absmax / 448 of the WHOLE batch.  The local
+    image rows (and the local rows of T = x W) differ between ranks, so the four absmax values are MAX-all-reduced
+    between the stages of the preparation; the text embeddings are already all-gathered and W is replicated (their
+    maxima are equal everywhere -- reducing them too keeps it one 16-byte collective).  Two collectives, forward only."""
+    amax = torch.zeros(4, dtype=torch.float32, device=x.device)
+    ops.fp8_stage(0, x, y_all, params, amax)
+    dist.all_reduce(amax, op=dist.ReduceOp.MAX, group=group)
+    ops.fp8_stage(1, x, y_all, params, amax)
+    dist.all_reduce(amax, op=dist.ReduceOp.MAX, group=group)
+    ops.fp8_stage(2, x, y_all, params, amax)
+
+
 def flat_views(like: Sequence[torch.Tensor]):
     """One contiguous buffer and per-tensor views into it: the parameter gradients of a step travel in ONE all-reduce
     (six separate latency-bound collectives for the concat-MLP critic otherwise)."""
@@ -172,8 +206,14 @@ class GlobalBatchCriticFn(torch.autograd.Function):
         need_grad = any(t.requires_grad for t in (x, y) + tuple(params))
         y_all = _all_gather_rows(y, group)
         sid_all = _all_gather_rows(sid_rows, group)
-        record, saved = ops.forward(x.contiguous(), y_all, [p.contiguous() for p in params], sid_rows.contiguous(),
-                                    sid_all, rank * br, estimator, precision, need_grad)
+        x = x.contiguous()
+        params_c = [p.contiguous() for p in params]
+        if precision == _hip.MI_PREC_FP8:
+            if not hasattr(ops, "fp8_stage"):
+                raise ValueError('precision="fp8" on a sharded batch needs an ops object with fp8_stage (bilinear critic)')
+            fp8_global_scales(ops, x, y_all, params_c, group)
+        record, saved = ops.forward(x, y_all, params_c, sid_rows.contiguous(), sid_all, rank * br, estimator, precision,
+                                    need_grad)
         records = _all_gather_rows(record.reshape(1, -1), group)  # [G, 8], rank order
         loss, stats = ops.merge(records, world * br, estimator)
         ctx.ops, ctx.group, ctx.saved = ops, group, saved
@@ -269,6 +309,10 @@ class GlobalBatchGraphStep:
             self._out = (self.grad_x, self.grad_y_partial, self.grad_params)
         self.graph_fwd = self.graph_bwd = None
         self._gather_inputs()
+        if self.prec == _hip.MI_PREC_FP8:
+            if not hasattr(self.ops, "fp8_stage"):
+                raise ValueError('precision="fp8" on a sharded batch needs the bilinear critic')
+            capture = False  # the fp8 preparation holds collectives (global scales): issued eagerly
         if not (capture and on_gpu):
             return  # eager: the same calls issued one by one (the gloo tests on the CPU, `bench.py --graph off`)
         torch.cuda.synchronize()
@@ -294,6 +338,8 @@ class GlobalBatchGraphStep:
         dist.all_gather_into_tensor(self.sid_all, self.sid, group=self.group)
 
     def _forward(self):
+        if self.prec == _hip.MI_PREC_FP8:  # (two tiny MAX all-reduces inside: this section is never captured in that mode)
+            fp8_global_scales(self.ops, self.x, self.y_all, self.params, self.group)
         self.record, self.saved = self.ops.forward(self.x, self.y_all, self.params, self.sid, self.sid_all,
                                                    self.rank * self.x.shape[0], self.est, self.prec, True)
 

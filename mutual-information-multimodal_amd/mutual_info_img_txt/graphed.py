@@ -42,6 +42,7 @@ class GraphedMiStep:
         if isinstance(critic, _model.BilinearCritic):
             self.kind = "bilinear"
             self.params: List[torch.Tensor] = [critic.weight]
+            self.prec = _hip.resolve_precision(precision, True, (self.b, self.dx, self.dy))  # "f32" -> bf16x3 here
         elif isinstance(critic, _model.SeparableCritic):
             raise ValueError("SeparableCritic: project the embeddings first (its projections are ordinary modules) and "
                              "build the step with critic=None on the projected widths")

@@ -307,8 +307,10 @@ def fused_mi_bound(embedding_img: torch.Tensor, embedding_txt: torch.Tensor, stu
     ``SeparableCritic`` from ``mutual_info_img_txt.model`` (extensions).  Returns the loss (shape [1] for "dv",
     [] for "infonce", as the reference) and optionally the [B,B] score matrix S[i,j] = critic(img_i, txt_j).
 
-    ``precision`` defaults to "f32" (exact fp32 products on the fp32-input MFMA): the reference critic is fp32
-    throughout and this is the mode whose gradients match it.  "bf16" (bf16 MFMA operands, fp32
+    ``precision`` defaults to "f32": the reference critic is fp32 throughout and this is the mode whose results match it
+    within the stated fp32 tolerances.  For the concat-MLP and separable critics it means exact fp32
+    products on the fp32-input MFMA; for ``BilinearCritic`` (sizes multiples of 8) it runs the "bf16x3" scheme below, which
+    meets the same tolerances at several times the speed -- pass "f32_exact" to insist on exact fp32 products.  "bf16" (bf16 MFMA operands, fp32
     accumulate) is the fast mode; it moves the gradients of this heavily cancelling loss by up to a few percent of
     max|grad| against the fp32 reference and must be asked for explicitly.  "bf16x3" (BilinearCritic only) splits every
     operand into two bf16 parts and spends three bf16 MFMAs per product: fp32-grade gradients at several times the speed
@@ -327,6 +329,9 @@ def fused_mi_bound(embedding_img: torch.Tensor, embedding_txt: torch.Tensor, stu
         embedding_txt = embedding_txt.float()
     code = _estimator_code(estimator)
     prec = _precision_code(precision)
+    if isinstance(critic, _model.BilinearCritic) and embedding_img.dim() == 2 and embedding_txt.dim() == 2:
+        # "f32" on the bilinear critic: fp32-grade results from three bf16 MFMAs per product (_hip.resolve_precision)
+        prec = _hip.resolve_precision(precision, True, (embedding_img.shape[0], embedding_img.shape[1], embedding_txt.shape[1]))
     if embedding_img.dim() != 2 or embedding_txt.dim() != 2 or embedding_img.shape[0] != embedding_txt.shape[0]:
         raise ValueError("embedding_img / embedding_txt must be [B, d_img] / [B, d_txt]")
     sid = study_id_codes(study_id, embedding_img.device)

@@ -141,3 +141,79 @@ def run(rank, world, port, b_local, d, estimator, out_dir):
     torch.save({"loss": loss.detach(), "dx": xl.grad, "dy": yl.grad, "dw": wl.grad}, os.path.join(out_dir, f"rank{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
+
+
+class OracleFp8Ops:
+    """CPU stand-in for the fp8 mode's local kernels (csrc/mi_fp8.h), staged like the product's (fp8_stage 0 / 1 / 2 with
+    the caller's MAX all-reduces of `amax` in between), restating oracle.mi_oracle.bilinear_step_fp8 for one row block."""
+
+    def fp8_stage(self, stage, x, y_all, params, amax):
+        from oracle import mi_oracle as orc
+        (w,) = params
+        f32 = torch.float32
+        if stage == 0:
+            amax[0], amax[1], amax[2], amax[3] = x.float().abs().max(), y_all.float().abs().max(), w.float().abs().max(), 0.0
+            return
+        if stage == 1:
+            sx, sy, sw = ((amax[k] / torch.tensor(orc.E4M3_MAX, dtype=f32)).float() for k in range(3))
+            self.qx = orc.quant_e4m3(x.to(f32) / sx).double()
+            self.qy = orc.quant_e4m3(y_all.to(f32) / sy).double()
+            self.qw = orc.quant_e4m3(w.to(f32) / sw).double()
+            self.sx, self.sy, self.sw = sx.double(), sy.double(), sw.double()
+            self.t = (self.sx * self.sw) * (self.qx @ self.qw)
+            amax[3] = self.t.float().abs().max()
+            return
+        st = (amax[3] / torch.tensor(orc.E4M3_MAX, dtype=f32)).float()
+        self.qt = orc.quant_e4m3(self.t.to(f32) / st).double()
+        self.st = st.double()
+
+    def forward(self, x, y_all, params, sid_rows, sid_all, row_offset, estimator, precision, need_grad):
+        s = (self.st * self.sy) * (self.qt @ self.qy.t())
+        br, b = s.shape
+        diag = (torch.arange(br)[:, None] + row_offset) == torch.arange(b)[None, :]
+        neg = (~diag) & (sid_rows[:, None] != sid_all[None, :])
+        m = s[neg].max()
+        cnt = int(neg.sum())
+        rec = torch.tensor([float(m), float(torch.exp(s[neg] - m).sum()), float(s[diag].sum()), float(cnt & 0xFFFFFF),
+                            float(cnt >> 24), 0, 0, 0], dtype=torch.float64)
+        return rec, (s, diag, neg)
+
+    merge = OracleBilinearOps.merge
+
+    def backward(self, saved, stats, grad_out):
+        from oracle import mi_oracle as orc
+        s, diag, neg = saved
+        lse, n_pos = stats[0], stats[1]
+        g = (torch.where(neg, torch.exp(s - lse), torch.zeros_like(s)) - diag.to(s.dtype) / n_pos) * grad_out.to(s.dtype)
+        gb = orc.round_bf16(g)
+        dt = orc.round_bf16(self.sy * (gb @ self.qy))
+        return self.sw * (dt @ self.qw.t()), self.st * (gb.t() @ self.qt), [self.sx * (self.qx.t() @ dt)]
+
+
+def run_fp8(rank, world, port, b_local, d, estimator, out_dir, staged):
+    """BASELINE configs[4]'s exchange: fp8 mode on a sharded batch, the scales made global by two MAX all-reduces."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from mutual_info_img_txt.distributed import GlobalBatchGraphStep, global_batch_mi_bound
+    from oracle import mi_oracle as orc
+    b = b_local * world
+    x, y, sid, _ = orc.synthetic_case(b, d, d, h1=8, h2=8, salt=31, dup=True, dtype=torch.float64)
+    x[b - 1] *= 3.0   # the largest image entry lives on the LAST rank: local scales would differ between the ranks
+    w = orc.hash_uniform((d, d), 77, torch.float64)
+    codes = torch.from_numpy(orc.sid_to_int(sid))
+    sl = slice(rank * b_local, (rank + 1) * b_local)
+    ops = OracleFp8Ops()
+    if staged:
+        st = GlobalBatchGraphStep(x[sl].contiguous(), y[sl].contiguous(), codes[sl].contiguous(), [w.clone()], estimator, "fp8",
+                                  critic="bilinear", group=dist.group.WORLD, ops=ops, capture=False)
+        loss = st.step()
+        out = {"loss": loss.detach().reshape(-1), "dx": st.grad_x, "dy": st.grad_y, "dw": st.grad_params[0].clone()}
+    else:
+        xl, yl, wl = (t.clone().requires_grad_(True) for t in (x[sl], y[sl], w))
+        loss = global_batch_mi_bound(xl, yl, codes[sl].contiguous(), [wl], estimator, "fp8", critic="bilinear",
+                                     group=dist.group.WORLD, ops=ops)
+        loss.sum().backward()
+        out = {"loss": loss.detach().reshape(-1), "dx": xl.grad, "dy": yl.grad, "dw": wl.grad}
+    torch.save(out, os.path.join(out_dir, f"rank{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()

@@ -10,7 +10,7 @@ pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-@pytest.mark.parametrize("kind,precision", [("bilinear", "bf16"), ("bilinear", "f32"), ("concat_mlp", "f32"),
+@pytest.mark.parametrize("kind,precision", [("bilinear", "bf16"), ("bilinear", "f32"), ("bilinear", "f32_exact"), ("concat_mlp", "f32"),
                                             ("concat_mlp", "bf16")])
 def test_fused_mi_bound_forward_backward_capture(kind, precision):
     r = subprocess.run([sys.executable, os.path.join(HERE, "capture_worker.py"), kind, precision], capture_output=True,

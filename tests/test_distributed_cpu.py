@@ -62,3 +62,27 @@ def test_concat_exchange_two_ranks_equals_single_process(tmp_path, staged):
     for a, c in zip(outs[0]["dparams"], outs[1]["dparams"]):
         assert torch.equal(a, c)
     assert torch.equal(outs[0]["loss"], outs[1]["loss"])
+
+
+@pytest.mark.parametrize("staged", [False, True])
+def test_fp8_global_scales_two_ranks_equals_single_process(tmp_path, staged):
+    """BASELINE configs[4] (fp8 critic on 8 GPUs) needs per-tensor scales of the WHOLE batch: the sharded path makes them
+    global with two MAX all-reduces between the stages of the fp8 preparation (distributed.fp8_global_scales).  Two gloo
+    ranks with an oracle-backed ops object staged exactly like the product's against the single-process fp8 oracle; the
+    largest image entry sits on rank 1 only, so rank-local scales would give different numbers."""
+    world, b_local, d = 2, 8, 16
+    mp.spawn(dist_worker.run_fp8, args=(world, _free_port(), b_local, d, "infonce", str(tmp_path), staged), nprocs=world,
+             join=True)
+    b = world * b_local
+    x, y, sid, _ = orc.synthetic_case(b, d, d, h1=8, h2=8, salt=31, dup=True, dtype=torch.float64)
+    x[b - 1] *= 3.0
+    w = orc.hash_uniform((d, d), 77, torch.float64)
+    ref = orc.bilinear_step_fp8(x, y, w, sid, "infonce")
+    outs = [torch.load(os.path.join(tmp_path, f"rank{r}.pt"), weights_only=True) for r in range(world)]
+    for r, o in enumerate(outs):
+        sl = slice(r * b_local, (r + 1) * b_local)
+        np.testing.assert_allclose(o["loss"].numpy().reshape(-1), ref["loss"].numpy().reshape(-1), rtol=1e-9, atol=1e-9)
+        np.testing.assert_allclose(o["dx"].numpy(), ref["dx"][sl].numpy(), rtol=1e-8, atol=1e-12)
+        np.testing.assert_allclose(o["dy"].numpy(), ref["dy"][sl].numpy(), rtol=1e-8, atol=1e-12)
+        np.testing.assert_allclose(o["dw"].numpy(), ref["dw"].numpy(), rtol=1e-8, atol=1e-12)
+    assert torch.equal(outs[0]["loss"], outs[1]["loss"]) and torch.equal(outs[0]["dw"], outs[1]["dw"])

@@ -98,3 +98,63 @@ def test_fp8_rejected_where_not_implemented(dev):
         _hip.call("mi_bilinear_fwd", dev, xs.data_ptr(), xs.data_ptr(), w.data_ptr(), sid.data_ptr(), sid.data_ptr(), 32, 32, 0,
                   24, 24, 0, _hip.MI_PREC_FP8, 1, loss.data_ptr(), stats.data_ptr(), rec.data_ptr(), None, ws.data_ptr(),
                   ws.numel())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("b,d,G", [(512, 256, 4), (1024, 1024, 8)])
+def test_fp8_row_blocks_with_global_scales(dev, b, d, G):
+    """BASELINE configs[4] is an 8-GPU configuration: a rank's row block must be quantised with the scales of the WHOLE
+    batch.  One GPU plays all G ranks through the real kernels and the staged preparation (mi_bilinear_fp8_stage), the MAX
+    all-reduce of the four absmax values done by hand; the result must match the single-GPU fp8 step (same quantised
+    operands: equal up to fp32 summation order) and the quantised oracle at the stated fp8 tolerances."""
+    from mutual_info_img_txt import _hip, mi_critics
+    from mutual_info_img_txt.distributed import HipBilinearOps
+    from mutual_info_img_txt.model import BilinearCritic
+    gen = torch.Generator().manual_seed(b + d)
+    x = torch.randn(b, d, generator=gen)
+    x[b - 1] *= 3.0  # the image absmax lives in the last row block only
+    y = torch.randn(b, d, generator=gen)
+    w = torch.randn(d, d, generator=gen) * (0.3 / math.sqrt(d))
+    sid = torch.tensor(_dup_ids(b))
+    est, code, prec = "infonce", _hip.ESTIMATORS["infonce"], _hip.MI_PREC_FP8
+    xd, yd, wd, sd = x.to(dev), y.to(dev), w.to(dev), sid.to(dev)
+    br = b // G
+    ops = [HipBilinearOps() for _ in range(G)]
+    amax = [torch.zeros(4, device=dev) for _ in range(G)]
+    blocks = [xd[g * br:(g + 1) * br].contiguous() for g in range(G)]
+    for stage in (0, 1, 2):
+        if stage:
+            glob = torch.stack(amax).max(dim=0).values  # what dist.all_reduce(op=MAX) leaves on every rank
+            for a in amax:
+                a.copy_(glob)
+        for g in range(G):
+            ops[g].fp8_stage(stage, blocks[g], yd, [wd], amax[g])
+    assert float(amax[0][0]) == float(x.abs().max())
+    outs = [ops[g].forward(blocks[g], yd, [wd], sd[g * br:(g + 1) * br].contiguous(), sd, g * br, code, prec, True) for g in range(G)]
+    loss, stats = ops[0].merge(torch.stack([o[0] for o in outs]), b, code)
+    go = torch.ones(1, device=dev)
+    gx, gy, gw = [], torch.zeros_like(yd), torch.zeros_like(wd)
+    for g in range(G):
+        a, c, (e,) = ops[g].backward(outs[g][1], stats, go)
+        gx.append(a)
+        gy += c
+        gw += e
+    gx = torch.cat(gx)
+    # the single-GPU step on the same batch
+    critic = BilinearCritic(d, d)
+    with torch.no_grad():
+        critic.weight.copy_(w)
+    critic.to(dev)
+    xl, yl = xd.clone().requires_grad_(True), yd.clone().requires_grad_(True)
+    l1 = mi_critics.fused_mi_bound(xl, yl, sd, critic, est, precision="fp8")
+    l1.backward()
+    torch.cuda.synchronize()
+    assert abs(float(loss) - float(l1)) < 1e-5 * max(1.0, abs(float(l1)))
+    for got, ref in ((gx, xl.grad), (gy, yl.grad), (gw, critic.weight.grad)):
+        assert float((got - ref).abs().max()) <= 2e-3 * float(ref.abs().max())  # bf16 roundings of G / dT per row block
+    o = orc.bilinear_step_fp8(x, y, w, sid, est)
+    sc = max(float(o["scores"].abs().max()), 1.0)
+    assert abs(float(loss) - float(o["loss"].sum())) < 2e-3 * sc
+    for name, got, ref in (("dx", gx, o["dx"]), ("dy", gy, o["dy"]), ("dw", gw, o["dw"])):
+        err = float((got.cpu().double() - ref).abs().max()) / float(ref.abs().max())
+        assert err < 2e-2, (name, err)

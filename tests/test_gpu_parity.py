@@ -200,7 +200,8 @@ def _bilinear_case(b, dx, dy, salt, dup):
 # fp32 MFMA mode: exact fp32 products; tolerance |d| <= 2e-5*scale for scores, 3e-5 for the loss, 2e-4*max|grad| for grads
 @pytest.mark.parametrize("b,dx,dy,dup", [(96, 40, 72, True), (128, 128, 128, False), (200, 64, 48, True), (8, 16, 16, False)])
 @pytest.mark.parametrize("est", ["dv", "infonce"])
-def test_bilinear_f32_vs_oracle(dev, b, dx, dy, dup, est):
+@pytest.mark.parametrize("precision", ["f32_exact", "f32"])  # "f32" on this critic = the bf16x3 scheme where sizes are multiples of 8
+def test_bilinear_f32_vs_oracle(dev, b, dx, dy, dup, est, precision):
     from mutual_info_img_txt import mi_critics
     from mutual_info_img_txt.model import BilinearCritic
     x, y, sid, w = _bilinear_case(b, dx, dy, b + dx, dup)
@@ -209,7 +210,7 @@ def test_bilinear_f32_vs_oracle(dev, b, dx, dy, dup, est):
         critic.weight.copy_(w)
     critic.to(dev)
     xl, yl = x.to(dev).requires_grad_(True), y.to(dev).requires_grad_(True)
-    loss, scores = mi_critics.fused_mi_bound(xl, yl, sid, critic, est, precision="f32", return_scores=True)
+    loss, scores = mi_critics.fused_mi_bound(xl, yl, sid, critic, est, precision=precision, return_scores=True)
     loss.sum().backward()
     o = orc.matrix_step(lambda a, c, ww: orc.bilinear_scores(a, c, ww), [x.double(), y.double(), w.double()], sid, est)
     assert tuple(loss.shape) == ((1,) if est == "dv" else ())
@@ -496,7 +497,7 @@ def test_concat_bf16_backward_vs_rounded_oracle(dev, b, dx, dy, h1, h2, dup):
 
 # ------------------------------------------------------------------------------------------------ row-block sharding
 @pytest.mark.parametrize("critic,precision,b,d,G", [
-    ("bilinear", "f32", 192, 64, 3), ("bilinear", "bf16", 192, 64, 3), ("concat_mlp", "f32", 192, 64, 3),
+    ("bilinear", "f32_exact", 192, 64, 3), ("bilinear", "f32", 192, 64, 3), ("bilinear", "bf16", 192, 64, 3), ("concat_mlp", "f32", 192, 64, 3),
     ("concat_mlp", "bf16", 192, 64, 3),
     # BASELINE config 4's sharding (8 ranks x 512 rows of a 4096 batch) and a 4-rank split: these row-block shapes take
     # the 128-tile score / G kernels and the two-problem long-K kernel with problems of different K (B against B/G)
@@ -538,7 +539,7 @@ def test_row_block_sharding_equals_full_batch(dev, critic, precision, b, d, G):
     lg, sg, gxg, gyg, gpg = run(G)
     assert s1["n_neg"] == sg["n_neg"] and s1["n_pos"] == sg["n_pos"] == b
     assert abs(float(l1) - float(lg)) < 2e-6 * max(1.0, abs(float(l1)))
-    tol = 2e-5 if precision == "f32" else 1e-2  # bf16: P is rounded against per-wave reference points, dT per row block
+    tol = 2e-5 if precision in ("f32", "f32_exact") else 1e-2  # bf16: P is rounded against per-wave reference points, dT per row block
     for a, c in [(gx1, gxg), (gy1, gyg)] + list(zip(gp1, gpg)):
         scale = max(float(a.abs().max()), 1e-12)
         assert float((a - c).abs().max()) <= tol * scale + 1e-7

@@ -105,7 +105,7 @@ def test_config1_separable_bf16(dev, dup):
 
 
 # ------------------------------------------------------------------------------------------------ fp32 parity at size
-@pytest.mark.parametrize("precision", ["f32", "bf16x3"])
+@pytest.mark.parametrize("precision", ["f32_exact", "bf16x3"])
 @pytest.mark.parametrize("b,d", [(1024, 512), (4096, 512)])
 def test_bilinear_f32_full_size_vs_fp64_oracle(dev, b, d, precision):
     """The parity modes at BASELINE configs 3 / 4 sizes against the UNROUNDED fp64 oracle, at DESIGN.md section 2's fp32
