@@ -19,7 +19,7 @@ One JSON line on stdout (rank 0): the driver's contract (`value` from exactly K 
 plus `timing` (median / p10 / p90 of >= 50 individually hipEvent-timed steps, graph and eager), `roofline` (dominant
 kernel, HIP-event timed through the library's profiling hook; measured HBM bytes and matrix-pipe busy fraction from the
 newest committed PMC pass of the SAME kernel sources), `parity_mode` (the same step in the modes held to fp32 tolerances:
-"f32" and "bf16x3"), `fp8_mode` (BASELINE configs[4] on one GPU: B = 8192, d = 1024), `secondary` (the reference's own
+"f32_exact" and "bf16x3"), `fp8_mode` (BASELINE configs[4] on one GPU: B = 8192, d = 1024), `secondary` (the reference's own
 critic, make_mlp(2d,[1024,512])) and `cpu_baseline` (the oracle timed on this box's host cores, rank 0, N = 1 only).
 """
 import argparse
@@ -45,8 +45,10 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3,  # dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md
+               "f32_exact": 157.3,       # v_mfma_f32_32x32x2_f32 products ("f32" on the bilinear critic runs bf16x3)
                "bf16x3": 2500.0 / 3,     # three bf16 MFMAs per algorithmic product
-               "fp8": 2500.0}            # non-scaled fp8 MFMA runs at the bf16 rate; the backward is bf16
+               "fp8": 5000.0}            # the dense fp8 peak (MX-scaled fp8 MFMA); this build's forward products use the
+                                         # non-scaled v_mfma_f32_32x32x16_fp8_fp8 (bf16 rate) and a bf16 backward
 PEAK_HBM_GBS = 8000.0
 
 
@@ -59,11 +61,12 @@ def parse_args():
     p.add_argument("--dim", type=int, default=512)
     p.add_argument("--critic", default="bilinear", choices=["bilinear", "concat_mlp"])
     p.add_argument("--estimator", default="infonce", choices=["dv", "infonce"])
-    p.add_argument("--precision", default="bf16", choices=["bf16", "f32", "bf16x3", "fp8"])
-    p.add_argument("--graph", default="auto", choices=["auto", "on", "off"],
+    p.add_argument("--precision", default="bf16", choices=["bf16", "f32", "f32_exact", "bf16x3", "fp8"])
+    p.add_argument("--graph", default="auto", choices=["auto", "on", "off", "full"],
                    help="on: replay the step from a hipGraph (one GPU: GraphedMiStep; N GPUs: the two compute sections "
                         "are graphs, the RCCL collectives stay eager between them).  off: the same C-ABI calls issued one "
-                        "by one.  auto (default): one GPU times both during warm-up and keeps the faster; N GPUs = on")
+                        "by one.  auto (default): one GPU times both during warm-up and keeps the faster; N GPUs = off.  full (N GPUs, "
+                        "opt-in): ONE graph per step with the RCCL collectives captured in it")
     p.add_argument("--timed-iters", type=int, default=50, help="individually hipEvent-timed steps for the median (>= 50)")
     p.add_argument("--no-secondary", action="store_true")
     p.add_argument("--secondary-steps", type=int, default=5)
@@ -212,7 +215,8 @@ class Stepper:
             if kind != "bilinear":
                 params[4] = params[4].reshape(-1)
             self.step_obj = GlobalBatchGraphStep(x, y, sid, [p.detach() for p in params], args.estimator, precision,
-                                                 critic=kind, group=group, capture=bool(graph))
+                                                 critic=kind, group=group,
+                                                 capture="full" if args.graph == "full" else bool(graph))
             self.eager_obj = self.step_obj if not graph else None
         else:
             self.step_obj = GraphedMiStep(self.critic, batch, d, d, args.estimator, precision, device, capture=bool(graph))
@@ -316,6 +320,9 @@ def profile_kernels(stepper, steps):
 # profiling-hook kernel name -> substring of the rocprofv3 kernel name in profiles/*_pmc_traffic.json
 PMC_KERNEL_OF = {
     "bilinear fused S | P Y | P^T T": "bilinear_flash_kernel",
+    "bilinear sums -> dT, dY | dX = dT W^T": "flash_tail_kernel",
+    "bilinear sums -> loss, dT, dY | dX = dT W^T": "flash_tail_kernel",
+    "bilinear dW = X^T dT": "bilinear_dw_kernel",
     "bilinear dT = G Y | dY = G^T T": "gemm_bf16_pipe_kernel",
     "bilinear G": "gemm_bf16_big_kernel<mi::EpiGradScore2>",
     "bilinear score+LSE": "gemm_bf16_big_kernel<mi::EpiScoreLse2>",
@@ -377,6 +384,31 @@ def roofline_of(kernels, br, b, d, precision):
             "frac": round(achieved / peak, 4), "traffic": c["bytes"] if ok else None,
             "mfma_busy_frac": c.get("mfma_busy_frac") if ok else None, "counters": c,
             "avg_us": round(k["ms_avg"] * 1e3, 2), "flops_per_launch": fl}
+
+
+def fp8_roofline(kernels, b, d):
+    """fp8 mode: the dominant kernel of the step against the peak of the MFMA it runs -- the dense fp8 peak (5 PFLOP/s) for
+    the kernels whose products are fp8 (score+LSE, G, T), the bf16 peak for the bf16 backward contractions."""
+    if not kernels:
+        return None
+    name = max(kernels, key=lambda k: kernels[k]["ms_total"])
+    k = kernels[name]
+    two = "|" in name
+    if name in ("fp8 score+LSE", "fp8 G") or two or name.startswith("fp8 mode dT") or name.startswith("fp8 mode dY"):
+        fl = (4.0 if two else 2.0) * b * b * d
+    elif name in ("fp8 T = X W", "fp8 mode dW = X^T dT", "fp8 mode dX = dT W^T"):
+        fl = 2.0 * b * d * d
+    else:
+        fl = 0.0
+    fp8_products = name in ("fp8 score+LSE", "fp8 G", "fp8 T = X W")
+    peak = PEAK_TFLOPS["fp8"] if fp8_products else PEAK_TFLOPS["bf16"]
+    if fl <= 0:
+        return {"kernel": name, "bound": "hbm", "achieved": None, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": None,
+                "traffic": None, "avg_us": round(k["ms_avg"] * 1e3, 2)}
+    achieved = fl / (k["ms_avg"] * 1e-3) / 1e12
+    return {"kernel": name, "bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
+            "frac": round(achieved / peak, 4), "traffic": None, "avg_us": round(k["ms_avg"] * 1e3, 2),
+            "flops_per_launch": fl, "operands": "fp8 e4m3" if fp8_products else "bf16"}
 
 
 def cpu_baseline(kind, args):
@@ -451,7 +483,7 @@ def main():
         raise SystemExit("--batch must be divisible by the number of GPUs")
     from mutual_info_img_txt import _hip
     _hip.load()
-    want_graph = args.graph in ("on", "auto")
+    want_graph = args.graph in ("on", "auto", "full")
     b, d, br = args.batch, args.dim, args.batch // world
 
     def run(kind, steps, warmup, precision=None, timed_iters=0, batch=None, dim=None):
@@ -467,7 +499,8 @@ def main():
     ms = elapsed / args.steps * 1e3
     flops = algorithmic_flops(args.critic, b, d, d)
     graph_mode = "none (direct C-ABI calls)" if st.use_eager else \
-        ("compute sections; collectives eager between them" if st.dist_mode else "one graph: forward + backward")
+        ("one graph: kernels + the five RCCL collectives" if st.dist_mode and args.graph == "full" else
+         "compute sections; collectives eager between them" if st.dist_mode else "one graph: forward + backward")
     out = {
         "metric": "img-txt pairs/sec (MI critic fwd+bwd), global-batch InfoNCE",
         "value": round(b / (ms * 1e-3), 1),
@@ -495,14 +528,16 @@ def main():
     }
     del st
     torch.cuda.empty_cache()
-    if not args.no_parity_mode and args.precision != "f32":
+    if not args.no_parity_mode and args.precision not in ("f32", "f32_exact"):
         # the same step in the mode whose results match the fp32 reference
         out["parity_mode"] = {}
-        notes = {"f32": "v_mfma_f32_32x32x2_f32: exact fp32 products, the mode tests/ holds to the fp32 tolerances of "
-                        "DESIGN.md section 2",
+        exact = "f32_exact" if args.critic == "bilinear" else "f32"  # "f32" on the bilinear critic resolves to bf16x3
+        notes = {exact: "v_mfma_f32_32x32x2_f32: exact fp32 products (precision=\"f32_exact\" on the bilinear critic; "
+                        "\"f32\" on the concat-MLP critic)",
                  "bf16x3": "two-part bf16 operands, three bf16 MFMAs per product (K tripled), fp32 accumulate: held to the "
-                           "same fp32 tolerances (tests/test_parity_configs.py); bilinear critic only"}
-        for mode in (["f32", "bf16x3"] if args.critic == "bilinear" and world == 1 else ["f32"]):
+                           "fp32 tolerances of DESIGN.md section 2 (tests/test_parity_configs.py); what precision=\"f32\" "
+                           "runs on the bilinear critic"}
+        for mode in ([exact, "bf16x3"] if args.critic == "bilinear" and world == 1 else [exact]):
             try:
                 n2 = max(3, args.steps // 10)
                 st2, el2, k2, _ = run(args.critic, n2, 2, precision=mode)
@@ -528,6 +563,8 @@ def main():
                             f"fwd+bwd, B={b8}, d={d8}; forward products on v_mfma_f32_32x32x16_fp8_fp8, backward on bf16 MFMA",
                 "value": round(b8 / (ms4 * 1e-3), 1), "unit": "pairs/s", "ms_per_step": round(ms4, 4), "steps": n8,
                 "loss": st4.loss(), "step_algorithmic_tflops": round(fl4 / (ms4 * 1e-3) / 1e12, 2),
+                "step_frac_of_peak": round(fl4 / (ms4 * 1e-3) / 1e12 / PEAK_TFLOPS["fp8"], 5),
+                "roofline": fp8_roofline(k4, b8, d8),
                 "kernels_us": {k: round(v["ms_avg"] * 1e3, 2) for k, v in sorted(k4.items(), key=lambda kv: -kv[1]["ms_total"])}}
             del st4
         except Exception as e:

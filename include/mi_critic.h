@@ -150,6 +150,14 @@ int mi_bilinear_bwd(const float* x, const float* y, const float* w, const int64_
                     float* grad_y, float* grad_w, void* workspace, size_t workspace_bytes,
                     int workspace_from_forward, void* stream);
 
+/* Sharded batches (b_rows < b): the part of the forward's preparation that depends on the rank's own rows only (bf16
+ * copies of X and W, T = X W), so that it runs while the all-gather of the text embeddings is in flight (SURVEY.md 8e:
+ * "overlap the gather with local work").  Then mi_bilinear_fwd(..., need_grad | 4, ...) on the SAME workspace (bit 2 of
+ * need_grad: the local part is prepared).  MI_ESHAPE where the shape does not take the fused kernels: call
+ * mi_bilinear_fwd alone then. */
+int mi_bilinear_prep_local(const float* x, const float* w, int64_t b_rows, int64_t b, int64_t d_img, int64_t d_txt,
+                           int precision, void* workspace, size_t workspace_bytes, void* stream);
+
 /* fp8 mode (MI_PREC_FP8) on a sharded batch: the per-tensor scales must be the whole batch's.  The forward's preparation
  * in three stages around the caller's two MAX all-reduces of amax_io (4 floats on the device: x, y, w, T):
  *   stage 0 -> amax_io[0..2] | all-reduce MAX | stage 1 -> amax_io[3] | all-reduce MAX | stage 2,

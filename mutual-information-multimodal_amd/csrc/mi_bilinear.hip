@@ -148,7 +148,16 @@ static GemmBf16Args one_problem(const bf16_t* a, int64_t lda, const bf16_t* b, i
 // ------------------------------------------------------------------------------------------------ fast path
 static int fast_prep_and_t(const float* x, const float* y, const float* w, const int64_t* sid_rows,
                            const int64_t* sid_cols, int64_t br, int64_t b, int64_t row_offset, int64_t dx, int64_t dy,
-                           const BilinearPlan& p, hipStream_t st) {
+                           const BilinearPlan& p, hipStream_t st, int part = 0) {
+  // part 1 / part 2: a sharded run prepares what depends on its OWN rows only (the conversions of X and W, T = X W)
+  // while the all-gather of the text embeddings is in flight (mi_bilinear_prep_local), and the rest -- the conversions of
+  // the gathered Y, the equal-id flags -- behind it.  Fused-kernel shapes only (the callers check p.fl.ok).
+  if (part == 2) {
+    CvtJobs rest{};
+    rest.j[1] = CvtJob{y, b, dy, p.yb, nullptr, 0, 0, p.yfb};
+    rest.dup = DupFlagJob{sid_rows, sid_cols, (int)(br / 32), (int)(b / 32), p.fl_dup[0], p.fl_dup[1], row_offset};
+    return launch_cvt_transpose3(rest, st, "bilinear prep Y, id flags");
+  }
   // With the fused B x B kernel nobody reads Y^T or T^T any more; instead T and Y get a fragment-major copy (the
   // kernel's stationary operand, loaded straight into MFMA B fragments) and the equal-id tile flags ride along.
   if (p.fl.ok) {
@@ -156,9 +165,9 @@ static int fast_prep_and_t(const float* x, const float* y, const float* w, const
     CvtJobs side{};
     // (with the two-launch tail nobody reads X^T row-major any more: only its fragment-major form)
     side.j[0] = CvtJob{x, br, dx, nullptr, p.tail ? nullptr : p.xtb, 0, 0, nullptr, 0, 0, p.xtfb};
-    side.j[1] = CvtJob{y, b, dy, p.yb, nullptr, 0, 0, p.yfb};
+    if (part == 0) side.j[1] = CvtJob{y, b, dy, p.yb, nullptr, 0, 0, p.yfb};
     side.j[2] = CvtJob{w, dx, dy, p.wb, nullptr, 0, 0, p.wfb};
-    side.dup = DupFlagJob{sid_rows, sid_cols, (int)(br / 32), (int)(b / 32), p.fl_dup[0], p.fl_dup[1], row_offset};
+    if (part == 0) side.dup = DupFlagJob{sid_rows, sid_cols, (int)(br / 32), (int)(b / 32), p.fl_dup[0], p.fl_dup[1], row_offset};
     const int rc1 = launch_prep_t(x, w, br, dy, dx, p.tb, p.tfb, side, st, "bilinear prep + T = X W");
     if (rc1 != MI_EINVAL) return rc1;
   }
@@ -166,9 +175,9 @@ static int fast_prep_and_t(const float* x, const float* y, const float* w, const
   const int ra = x3 == 3 ? 1 : 0, rb = x3 == 3 ? 2 : 0;  // bf16x3 roles of A-side and B-side operands
   CvtJobs jobs{};
   jobs.j[0] = CvtJob{x, br, dx, p.xb, p.xtb, 0, 0, nullptr, ra, ra, p.xtfb};
-  jobs.j[1] = CvtJob{y, b, dy, p.yb, p.fl.ok ? nullptr : p.ytb, 0, 0, p.fl.ok ? p.yfb : nullptr, rb, rb};
+  if (part == 0) jobs.j[1] = CvtJob{y, b, dy, p.yb, p.fl.ok ? nullptr : p.ytb, 0, 0, p.fl.ok ? p.yfb : nullptr, rb, rb};
   jobs.j[2] = CvtJob{w, dx, dy, p.wb, p.wtb, 0, 0, p.wfb, rb, rb};
-  if (p.fl.ok) jobs.dup = DupFlagJob{sid_rows, sid_cols, (int)(br / 32), (int)(b / 32), p.fl_dup[0], p.fl_dup[1], row_offset};
+  if (p.fl.ok && part == 0) jobs.dup = DupFlagJob{sid_rows, sid_cols, (int)(br / 32), (int)(b / 32), p.fl_dup[0], p.fl_dup[1], row_offset};
   int rc = launch_cvt_transpose3(jobs, st, "bilinear prep X Y W");
   if (rc) return rc;
   // T[i, c] = sum_a X[i, a] W[a, c]: A = Xb [br][dx], B = W^T [dy][dx]
@@ -238,7 +247,8 @@ static int bilinear_fwd_fast(const float* x, const float* y, const float* w, con
                              const int64_t* sid_cols, int64_t br, int64_t b, int64_t row_offset, int64_t dx, int64_t dy,
                              int estimator, int need_grad, float* loss_out, mi_stats* stats, float* partials_out,
                              float* scores_out, const BilinearPlan& p, hipStream_t st) {
-  int rc = fast_prep_and_t(x, y, w, sid_rows, sid_cols, br, b, row_offset, dx, dy, p, st);
+  // need_grad bit 2: mi_bilinear_prep_local already made the part of the preparation that needs neither Y nor the column ids
+  int rc = fast_prep_and_t(x, y, w, sid_rows, sid_cols, br, b, row_offset, dx, dy, p, st, (need_grad & 4) && p.fl.ok ? 2 : 0);
   if (rc) return rc;
   if (p.fl.ok) {
     rc = flash_stage(sid_rows, sid_cols, br, b, row_offset, dy, need_grad != 0, p, st);
@@ -623,6 +633,28 @@ int mi_bilinear_bwd(const float* x, const float* y, const float* w, const int64_
                                              grad_out, grad_x, grad_y, grad_w, p, st);
   return bilinear_bwd_impl<float, float>(x, y, w, sid_rows, sid_cols, b_rows, b, row_offset, d_img, d_txt, stats,
                                          grad_out, grad_x, grad_y, grad_w, p, st);
+}
+
+/* Sharded batches: the part of the forward's preparation that depends on the rank's OWN rows only -- the bf16 copies of
+ * X and W and T = X W -- so that it can run while the all-gather of the text embeddings is in flight.  Follow with
+ * mi_bilinear_fwd(..., need_grad | 4, ...) on the same workspace (bit 2: the local part is prepared).  Returns
+ * MI_ESHAPE where the shape does not take the fused kernels (the caller then simply calls mi_bilinear_fwd as usual). */
+int mi_bilinear_prep_local(const float* x, const float* w, int64_t b_rows, int64_t b, int64_t d_img, int64_t d_txt,
+                           int precision, void* workspace, size_t workspace_bytes, void* stream) {
+  MI_CHECK_ARG(x && w && workspace, "mi_bilinear_prep_local: null pointer");
+  int rc = check_common("mi_bilinear_prep_local", b_rows, b, 0, d_img, d_txt, precision);
+  if (rc) return rc;
+  Workspace ws(workspace, workspace_bytes);
+  BilinearPlan p = plan_bilinear(ws, b_rows, b, d_img, d_txt, precision);
+  if (!ws.ok()) {
+    set_error("mi_bilinear_prep_local: workspace too small (%zu < %zu)", workspace_bytes, ws.off);
+    return MI_EWORKSPACE;
+  }
+  if (!(fast_ok(b_rows, b, d_img, d_txt, precision, true) && p.fl.ok)) {
+    set_error("mi_bilinear_prep_local: shape / precision outside the fused kernels (call mi_bilinear_fwd alone)");
+    return MI_ESHAPE;
+  }
+  return fast_prep_and_t(x, nullptr, w, nullptr, nullptr, b_rows, b, 0, d_img, d_txt, p, (hipStream_t)stream, 1);
 }
 
 /* fp8 mode on a SHARDED batch: the per-tensor scales must be those of the whole batch.  The forward's preparation in

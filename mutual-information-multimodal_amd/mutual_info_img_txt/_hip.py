@@ -61,6 +61,7 @@ SIGNATURES = {
     "mi_bilinear_workspace_bytes": (_SZ, [_I64, _I64, _I64, _I64, _I]),
     "mi_bilinear_fwd": (c_int, [_P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I, _I, _I, _P, _P, _P, _P, _P, _SZ, _P]),
     "mi_bilinear_bwd": (c_int, [_P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I, _P, _P, _P, _P, _P, _P, _SZ, _I, _P]),
+    "mi_bilinear_prep_local": (c_int, [_P, _P, _I64, _I64, _I64, _I64, _I, _P, _SZ, _P]),
     "mi_bilinear_fp8_stage": (c_int, [_P, _P, _P, _I64, _I64, _I64, _I64, _I, _P, _P, _SZ, _P]),
     "mi_bilinear_step": (c_int, [_P, _P, _P, _P, _I64, _I64, _I64, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _SZ, _P]),
     "mi_separable_workspace_bytes": (_SZ, [_I64, _I64, _I64, _I64, _I64, _I]),
@@ -73,6 +74,9 @@ SIGNATURES = {
 }
 
 _lib: Optional[ctypes.CDLL] = None
+
+
+MI_ESHAPE = -2  # include/mi_critic.h
 
 
 class MiCriticError(RuntimeError):

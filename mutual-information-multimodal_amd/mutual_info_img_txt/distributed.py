@@ -15,6 +15,7 @@ The local compute is an ``ops`` object.  The product default runs the HIP kernel
 """
 from __future__ import annotations
 
+import os
 from typing import List, Optional, Sequence
 
 import torch
@@ -31,7 +32,28 @@ class HipBilinearOps:
     n_params = 1
 
     def __init__(self):
-        self._fp8_ws = None  # workspace of a staged fp8 preparation, handed on to forward()
+        self._fp8_ws = None    # workspace of a staged fp8 preparation, handed on to forward()
+        self._local_ws = None  # workspace in which prep_local() prepared the rank's own part, handed on to forward()
+
+    def prep_local(self, x, params, b, precision) -> bool:
+        """The part of the forward that needs neither the gathered text embeddings nor the gathered ids -- bf16 copies of
+        X and W, T = X W (mi_bilinear_prep_local) -- issued while the all-gather is in flight.  False where the shape or
+        precision does not take the fused kernels (forward() then does everything, as before)."""
+        lib = _hip.load()
+        (w,) = params
+        br, dx = x.shape
+        dy = w.shape[1]
+        if precision == _hip.MI_PREC_FP8:
+            return False
+        ws = _hip.workspace(lib.mi_bilinear_workspace_bytes(br, b, dx, dy, precision), x.device)
+        with torch.cuda.device(x.device):
+            rc = lib.mi_bilinear_prep_local(x.data_ptr(), w.data_ptr(), br, b, dx, dy, precision, ws.data_ptr(), ws.numel(),
+                                            torch.cuda.current_stream(x.device).cuda_stream)
+        if rc == _hip.MI_ESHAPE:
+            return False
+        _hip.check(rc, "mi_bilinear_prep_local")
+        self._local_ws = ws
+        return True
 
     def fp8_stage(self, stage, x, y_all, params, amax):
         """One stage of the fp8 mode's preparation (mi_bilinear_fp8_stage): ``amax`` (4 floats on the device: x, y, W, T)
@@ -56,6 +78,9 @@ class HipBilinearOps:
         if staged:
             ws, self._fp8_ws = self._fp8_ws, None
             need_grad = int(bool(need_grad)) | 2  # bit 1: the fp8 operands are staged in this workspace
+        elif self._local_ws is not None:
+            ws, self._local_ws = self._local_ws, None
+            need_grad = int(bool(need_grad)) | 4  # bit 2: prep_local() already ran in this workspace
         else:
             ws = _hip.workspace(lib.mi_bilinear_workspace_bytes(br, b, dx, dy, precision), dev)
         stats = _hip.new_stats(dev)
@@ -93,6 +118,45 @@ class HipBilinearOps:
                                        grad_out.data_ptr(), gx.data_ptr(), gy.data_ptr(), gw.data_ptr(), ws.data_ptr(),
                                        ws.numel(), 1)
         return gx, gy, [gw]
+
+
+class HipSeparableOps:
+    """S = (X Wg)(Y Wh)^T row block (BASELINE.json configs[1]); params = [Wg, Wh].  Every rank projects ALL text rows
+    (B d k flops, small beside the B^2 stage); d(Wh) and dY are partials over the row block like the bilinear dY."""
+    n_params = 2
+
+    def forward(self, x, y_all, params, sid_rows, sid_all, row_offset, estimator, precision, need_grad):
+        lib = _hip.load()
+        wg, wh = params
+        br, dx = x.shape
+        b, dy = y_all.shape
+        k = wg.shape[1]
+        dev = x.device
+        ws = _hip.workspace(lib.mi_separable_workspace_bytes(br, b, dx, dy, k, precision), dev)
+        stats = _hip.new_stats(dev)
+        loss = torch.empty(1, dtype=torch.float32, device=dev)
+        record = torch.empty(_hip.RECORD_FLOATS, dtype=torch.float32, device=dev)
+        _hip.call("mi_separable_fwd", dev, x.data_ptr(), y_all.data_ptr(), wg.data_ptr(), wh.data_ptr(), sid_rows.data_ptr(),
+                  sid_all.data_ptr(), br, b, row_offset, dx, dy, k, estimator, precision, int(bool(need_grad)),
+                  loss.data_ptr(), stats.data_ptr(), record.data_ptr(), ws.data_ptr(), ws.numel())
+        return record, (x, y_all, wg, wh, sid_rows, sid_all, row_offset, precision, ws)
+
+    def backward(self, saved, stats, grad_out, out=None):
+        x, y_all, wg, wh, sid_rows, sid_all, row_offset, precision, ws = saved
+        br, dx = x.shape
+        b, dy = y_all.shape
+        k = wg.shape[1]
+        if out is None:
+            gx, gy, gg, gh = (torch.empty_like(t) for t in (x, y_all, wg, wh))
+        else:
+            gx, gy, (gg, gh) = out
+        _hip.call("mi_separable_bwd", x.device, x.data_ptr(), y_all.data_ptr(), wg.data_ptr(), wh.data_ptr(),
+                  sid_rows.data_ptr(), sid_all.data_ptr(), br, b, row_offset, dx, dy, k, precision, stats.data_ptr(),
+                  grad_out.data_ptr(), gx.data_ptr(), gy.data_ptr(), gg.data_ptr(), gh.data_ptr(), ws.data_ptr(), ws.numel(),
+                  1)
+        return gx, gy, [gg, gh]
+
+    merge = HipBilinearOps.merge
 
 
 class HipConcatMlpOps:
@@ -140,11 +204,25 @@ class HipConcatMlpOps:
 # ----------------------------------------------------------------------------------------------------------
 # collectives (RCCL on GPUs; gloo in the CPU tests)
 # ----------------------------------------------------------------------------------------------------------
-def _all_gather_rows(t: torch.Tensor, group) -> torch.Tensor:
+def _all_gather_rows(t: torch.Tensor, group, async_op: bool = False):
     world = dist.get_world_size(group)
     out = torch.empty((world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
-    dist.all_gather_into_tensor(out, t.contiguous(), group=group)
-    return out
+    work = dist.all_gather_into_tensor(out, t.contiguous(), group=group, async_op=async_op)
+    return (out, work) if async_op else out
+
+
+def gather_under_local_work(ops, x, params, b, precision, gathers):
+    """Overlap: ``gathers`` = callables that START the all-gathers of the text
+    embeddings and ids (async: on RCCL's stream) and return their work handles; the part of the forward that depends on
+    this rank's own rows only (``ops.prep_local``: conversions of X and W, T = X W) is then issued on the compute stream,
+    and only after that the compute stream is made to wait for the gathers.  Ops objects without ``prep_local`` (the
+    concat-MLP critic, whose first layer's text half needs the gathered rows) just wait."""
+    works = [g() for g in gathers]
+    if hasattr(ops, "prep_local"):
+        ops.prep_local(x, params, b, precision)
+    for w in works:
+        if w is not None:
+            w.wait()
 
 
 def _reduce_scatter_rows(t: torch.Tensor, group) -> torch.Tensor:
@@ -204,10 +282,17 @@ class GlobalBatchCriticFn(torch.autograd.Function):
         rank = dist.get_rank(group)
         br = x.shape[0]
         need_grad = any(t.requires_grad for t in (x, y) + tuple(params))
-        y_all = _all_gather_rows(y, group)
-        sid_all = _all_gather_rows(sid_rows, group)
         x = x.contiguous()
         params_c = [p.contiguous() for p in params]
+        got = {}
+
+        def start(name, t):
+            def go():
+                got[name], work = _all_gather_rows(t, group, async_op=True)
+                return work
+            return go
+        gather_under_local_work(ops, x, params_c, world * br, precision, [start("y", y), start("sid", sid_rows)])
+        y_all, sid_all = got["y"], got["sid"]
         if precision == _hip.MI_PREC_FP8:
             if not hasattr(ops, "fp8_stage"):
                 raise ValueError('precision="fp8" on a sharded batch needs an ops object with fp8_stage (bilinear critic)')
@@ -256,7 +341,7 @@ def global_batch_mi_bound(embedding_img, embedding_txt, study_id_codes, critic_p
     embeddings and the (all-reduced) gradient w.r.t. the critic parameters."""
     from .mi_critics import _estimator_code, _precision_code
     if ops is None:
-        ops = {"bilinear": HipBilinearOps, "concat_mlp": HipConcatMlpOps}[critic]()
+        ops = {"bilinear": HipBilinearOps, "separable": HipSeparableOps, "concat_mlp": HipConcatMlpOps}[critic]()
     est = _estimator_code(estimator)
     prec = _precision_code(precision)
     loss, stats = GlobalBatchCriticFn.apply(ops, group, est, prec, study_id_codes, embedding_img, embedding_txt,
@@ -269,7 +354,8 @@ class GlobalBatchGraphStep:
     """Forward + backward of the global-batch bound for FIXED shapes and storage, with the two compute sections of a
     step replayed from hipGraphs and the collectives issued eagerly between them:
 
-        all-gather Y, ids | graph 1: local forward -> partial record | all-gather records |
+        all-gather Y, ids (graph 0 under them: bf16 X, W and T = X W of the rank's own rows) |
+        graph 1: rest of the local forward -> partial record | all-gather records |
         graph 2: rank-ordered merge + local backward | reduce-scatter dY, all-reduce d(params)
 
     Why: at global batch 4096 a rank's kernels take tens of microseconds, and launching them one by one from Python
@@ -286,7 +372,7 @@ class GlobalBatchGraphStep:
         self.group = group
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
-        self.ops = ops if ops is not None else {"bilinear": HipBilinearOps, "concat_mlp": HipConcatMlpOps}[critic]()
+        self.ops = ops if ops is not None else {"bilinear": HipBilinearOps, "separable": HipSeparableOps, "concat_mlp": HipConcatMlpOps}[critic]()
         self.est, self.prec = _estimator_code(estimator), _precision_code(precision)
         self.x, self.y, self.sid = x.detach(), y.detach(), sid
         self.params = [p.detach() for p in params]
@@ -307,8 +393,10 @@ class GlobalBatchGraphStep:
             self.grad_x = torch.empty_like(self.x)
             self.grad_y_partial = torch.empty_like(self.y_all)
             self._out = (self.grad_x, self.grad_y_partial, self.grad_params)
-        self.graph_fwd = self.graph_bwd = None
-        self._gather_inputs()
+        self.graph_fwd = self.graph_bwd = self.graph_local = self.graph_full = None
+        # MI_DIST_NO_OVERLAP=1: A/B switch of the measurements in profiles/README.md (the local part then runs inside forward)
+        self._has_local = hasattr(self.ops, "prep_local") and not os.environ.get("MI_DIST_NO_OVERLAP")
+        self._gather_inputs(local=False)
         if self.prec == _hip.MI_PREC_FP8:
             if not hasattr(self.ops, "fp8_stage"):
                 raise ValueError('precision="fp8" on a sharded batch needs the bilinear critic')
@@ -320,22 +408,58 @@ class GlobalBatchGraphStep:
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
+            self._prep_local()
             self._forward()
             self._merge_backward()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+        if capture == "full":
+            # ONE graph for the whole step, the five RCCL collectives captured with the kernels (RCCL calls are
+            # capturable stream work): the host issues a single launch per step instead of ~12 calls.  Opt-in: the
+            # capture of collectives could only be rehearsed with one rank on this project's one-GPU boxes.
+            self._reduce_scatter_out = torch.empty_like(self.y) if dist.get_backend(group) != "gloo" else None
+            with torch.cuda.stream(side):   # one eager pass of exactly the captured sequence (RCCL channel set-up)
+                self._whole_step()
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            dist.barrier(group=self.group)
+            self.graph_full = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph_full):
+                self._whole_step()
+            return
+        pool = torch.cuda.graph_pool_handle()
+        if self._has_local:
+            # the rank-local part as its own graph, replayed while the input all-gathers are in flight; its workspace is
+            # the one the forward graph goes on with (both captured from one pool, the tensor kept in self.saved)
+            local = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(local, pool=pool):
+                self._prep_local()
+            if getattr(self.ops, "_local_ws", None) is not None:
+                self.graph_local = local
         self.graph_fwd = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph_fwd):
+        with torch.cuda.graph(self.graph_fwd, pool=pool):
             self._forward()
         # the record gathered from every rank must exist before the second capture reads it
         dist.all_gather_into_tensor(self.records, self.record.reshape(1, -1), group=self.group)
         self.graph_bwd = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph_bwd, pool=self.graph_fwd.pool()):
+        with torch.cuda.graph(self.graph_bwd, pool=pool):
             self._merge_backward()
 
-    def _gather_inputs(self):
-        dist.all_gather_into_tensor(self.y_all, self.y, group=self.group)
-        dist.all_gather_into_tensor(self.sid_all, self.sid, group=self.group)
+    def _prep_local(self):
+        if self._has_local:
+            self.ops.prep_local(self.x, self.params, self.y_all.shape[0], self.prec)
+
+    def _gather_inputs(self, local: bool = True):
+        """The two input all-gathers, with the rank-local part of the forward issued while they are in flight.  Not
+        captured: in the graphed mode the local part is its own small graph (graph_local) replayed at the same place."""
+        works = [dist.all_gather_into_tensor(self.y_all, self.y, group=self.group, async_op=True),
+                 dist.all_gather_into_tensor(self.sid_all, self.sid, group=self.group, async_op=True)]
+        if local and self.graph_local is not None:
+            self.graph_local.replay()
+        elif local:
+            self._prep_local()
+        for w in works:
+            w.wait()
 
     def _forward(self):
         if self.prec == _hip.MI_PREC_FP8:  # (two tiny MAX all-reduces inside: this section is never captured in that mode)
@@ -357,9 +481,25 @@ class GlobalBatchGraphStep:
         if self.grad_flat is not None:
             dist.all_reduce(self.grad_flat, group=self.group)
 
+    def _whole_step(self):
+        self._gather_inputs()
+        self._forward()
+        dist.all_gather_into_tensor(self.records, self.record.reshape(1, -1), group=self.group)
+        self._merge_backward()
+        if self._reduce_scatter_out is not None:
+            dist.reduce_scatter_tensor(self._reduce_scatter_out, self.grad_y_partial, group=self.group)
+            self.grad_y = self._reduce_scatter_out
+        else:
+            self.grad_y = _reduce_scatter_rows(self.grad_y_partial, self.group)
+        if self.grad_flat is not None:
+            dist.all_reduce(self.grad_flat, group=self.group)
+
     def step(self):
         """all-gather Y, ids | local forward | all-gather records | merge + local backward | reduce-scatter dY, ONE
         all-reduce of the flat parameter-gradient buffer.  Five collectives per step, in this order on every rank."""
+        if self.graph_full is not None:
+            self.graph_full.replay()
+            return self.loss
         if self.graph_fwd is None:
             return self.step_eager()
         self._gather_inputs()

@@ -217,3 +217,65 @@ def run_fp8(rank, world, port, b_local, d, estimator, out_dir, staged):
     torch.save(out, os.path.join(out_dir, f"rank{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
+
+
+class OracleSplitBilinearOps(OracleBilinearOps):
+    """The split forward (mi_bilinear_prep_local + mi_bilinear_fwd with bit 2): T = X W from prep_local(), which must run
+    BEFORE the gathered rows are handed over -- forward() refuses to compute it itself and logs the order of the calls."""
+
+    def __init__(self):
+        self.t = None
+        self.calls = []
+
+    def prep_local(self, x, params, b, precision):
+        (w,) = params
+        self.calls.append(("prep_local", int(b)))
+        self.t = x @ w
+        return True
+
+    def forward(self, x, y_all, params, sid_rows, sid_all, row_offset, estimator, precision, need_grad):
+        assert self.t is not None, "forward() before prep_local(): the local part was not issued under the gather"
+        self.calls.append(("forward", int(y_all.shape[0])))
+        t, self.t = self.t, None
+        rec, saved = OracleBilinearOps.forward(self, x, y_all, params, sid_rows, sid_all, row_offset, estimator, precision, need_grad)
+        assert torch.equal(saved[3], t @ y_all.t())
+        return rec, saved
+
+
+def _separable_scorer(x, y_all, wg, wh):
+    return (x @ wg) @ (y_all @ wh).t()
+
+
+def run_variant(rank, world, port, b_local, d, estimator, out_dir, variant, staged):
+    """variant "split": the bilinear critic with the split forward; "separable": S = (X Wg)(Y Wh)^T sharded by rows."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from mutual_info_img_txt.distributed import GlobalBatchGraphStep, global_batch_mi_bound
+    from oracle import mi_oracle as orc
+    b = b_local * world
+    x, y, sid, _ = orc.synthetic_case(b, d, d, h1=8, h2=8, salt=21, dup=True, dtype=torch.float64)
+    if variant == "split":
+        params, ops, critic = [orc.hash_uniform((d, d), 99, torch.float64)], OracleSplitBilinearOps(), "bilinear"
+    else:
+        params = [orc.hash_uniform((d, 6), 41, torch.float64), orc.hash_uniform((d, 6), 42, torch.float64)]
+        ops, critic = OracleAutogradOps(_separable_scorer), "separable"
+    codes = torch.from_numpy(orc.sid_to_int(sid))
+    sl = slice(rank * b_local, (rank + 1) * b_local)
+    if staged:
+        st = GlobalBatchGraphStep(x[sl].contiguous(), y[sl].contiguous(), codes[sl].contiguous(), [p.clone() for p in params],
+                                  estimator, "f32", critic=critic, group=dist.group.WORLD, ops=ops, capture=False)
+        st.step()
+        loss = st.step()   # twice: the hand-over of the prepared part must work step after step
+        out = {"loss": loss.detach().reshape(-1), "dx": st.grad_x, "dy": st.grad_y, "dparams": [g.clone() for g in st.grad_params]}
+    else:
+        xl, yl = (t.clone().requires_grad_(True) for t in (x[sl], y[sl]))
+        pl = [p.clone().requires_grad_(True) for p in params]
+        loss = global_batch_mi_bound(xl, yl, codes[sl].contiguous(), pl, estimator, "f32", critic=critic,
+                                     group=dist.group.WORLD, ops=ops)
+        loss.sum().backward()
+        out = {"loss": loss.detach().reshape(-1), "dx": xl.grad, "dy": yl.grad, "dparams": [p.grad for p in pl]}
+    if variant == "split":
+        out["calls"] = [f"{n}:{v}" for n, v in ops.calls]
+    torch.save(out, os.path.join(out_dir, f"rank{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()

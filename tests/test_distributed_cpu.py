@@ -86,3 +86,37 @@ def test_fp8_global_scales_two_ranks_equals_single_process(tmp_path, staged):
         np.testing.assert_allclose(o["dy"].numpy(), ref["dy"][sl].numpy(), rtol=1e-8, atol=1e-12)
         np.testing.assert_allclose(o["dw"].numpy(), ref["dw"].numpy(), rtol=1e-8, atol=1e-12)
     assert torch.equal(outs[0]["loss"], outs[1]["loss"]) and torch.equal(outs[0]["dw"], outs[1]["dw"])
+
+
+@pytest.mark.parametrize("staged", [False, True])
+@pytest.mark.parametrize("variant", ["split", "separable"])
+def test_split_forward_and_separable_two_ranks(tmp_path, variant, staged):
+    """VERDICT r2 item 7.  "split": the rank-local part of the forward (ops.prep_local: T = X W) is issued between the
+    START of the input all-gathers and the wait for them, then forward() goes on from it -- same numbers as the
+    single-process oracle, and the call log shows prep_local before every forward.  "separable": BASELINE configs[1]'s
+    critic sharded by rows, two parameter gradients in the one flat all-reduce."""
+    world, b_local, d = 2, 6, 5
+    mp.spawn(dist_worker.run_variant, args=(world, _free_port(), b_local, d, "infonce", str(tmp_path), variant, staged),
+             nprocs=world, join=True)
+    b = world * b_local
+    x, y, sid, _ = orc.synthetic_case(b, d, d, h1=8, h2=8, salt=21, dup=True, dtype=torch.float64)
+    if variant == "split":
+        params = [orc.hash_uniform((d, d), 99, torch.float64)]
+        ref = orc.matrix_step(lambda a, c, ww: orc.bilinear_scores(a, c, ww), [x, y] + params, sid, "infonce")
+    else:
+        params = [orc.hash_uniform((d, 6), 41, torch.float64), orc.hash_uniform((d, 6), 42, torch.float64)]
+        ref = orc.matrix_step(lambda a, c, g, h: orc.separable_scores(a, c, g, h), [x, y] + params, sid, "infonce")
+    outs = [torch.load(os.path.join(tmp_path, f"rank{r}.pt"), weights_only=True) for r in range(world)]
+    for r, o in enumerate(outs):
+        sl = slice(r * b_local, (r + 1) * b_local)
+        np.testing.assert_allclose(o["loss"].numpy().reshape(-1), ref["loss"].numpy().reshape(-1), rtol=1e-6, atol=1e-6)
+        np.testing.assert_allclose(o["dx"].numpy(), ref["grads"][0][sl].numpy(), rtol=1e-8, atol=1e-12)
+        np.testing.assert_allclose(o["dy"].numpy(), ref["grads"][1][sl].numpy(), rtol=1e-8, atol=1e-12)
+        for got, want in zip(o["dparams"], ref["grads"][2:]):
+            np.testing.assert_allclose(got.numpy(), want.numpy(), rtol=1e-8, atol=1e-12)
+        if variant == "split":
+            want = ["prep_local:12", "forward:12"] * (2 if staged else 1)
+            assert o["calls"] == want, o["calls"]
+    assert torch.equal(outs[0]["loss"], outs[1]["loss"])
+    for a, c in zip(outs[0]["dparams"], outs[1]["dparams"]):
+        assert torch.equal(a, c)

@@ -177,6 +177,85 @@ def test_flash_row_blocks_equal_full_batch(dev, b, d, G):
     assert _rel(c1.cpu(), ob["dy"]) < 1e-2
 
 
+@pytest.mark.parametrize("b,d,G,prec", [(1024, 512, 4, "bf16"), (512, 256, 2, "bf16x3"), (256, 128, 2, "bf16")])
+def test_split_forward_equals_the_one_call(dev, b, d, G, prec):
+    """mi_bilinear_prep_local (bf16 X, W and T = X W of the rank's own rows -- what a sharded run issues while the text
+    all-gather is in flight) followed by mi_bilinear_fwd with bit 2 of need_grad, against mi_bilinear_fwd alone: same
+    kernels on the same values, so the record and all three gradients are bit-identical.  Y and the column ids are
+    written only AFTER prep_local returned (it must not have read them)."""
+    from mutual_info_img_txt.distributed import HipBilinearOps
+    from mutual_info_img_txt.mi_critics import _precision_code
+    gen = torch.Generator().manual_seed(b + d)
+    x = torch.randn(b, d, generator=gen).to(dev)
+    y = torch.randn(b, d, generator=gen).to(dev)
+    w = (torch.randn(d, d, generator=gen) * (0.25 / math.sqrt(d))).to(dev)
+    sid = torch.arange(b)
+    sid[3] = sid[b - 5]
+    sid = sid.to(dev)
+    pc = _precision_code(prec)
+    br = b // G
+    g = G - 1
+    xs, ss = x[g * br:(g + 1) * br].contiguous(), sid[g * br:(g + 1) * br].contiguous()
+    go = torch.ones(1, device=dev)
+    one = HipBilinearOps()
+    rec1, sv1 = one.forward(xs, y, [w], ss, sid, g * br, 1, pc, True)
+    two = HipBilinearOps()
+    y_late, sid_late = torch.full_like(y, float("nan")), torch.zeros_like(sid)
+    if prec != "bf16":  # the fp32-tolerance mode runs on the tiled kernels, not the fused one: declined, nothing staged
+        assert two.prep_local(xs, [w], b, pc) is False and two._local_ws is None
+        return
+    assert two.prep_local(xs, [w], b, pc) is True
+    y_late.copy_(y)
+    sid_late.copy_(sid)
+    rec2, sv2 = two.forward(xs, y_late, [w], ss, sid_late, g * br, 1, pc, True)
+    assert two._local_ws is None
+    loss, stats = one.merge(rec1.reshape(1, -1), br, 1)
+    a1, c1, (e1,) = one.backward(sv1, stats, go)
+    a2, c2, (e2,) = two.backward(sv2, stats, go)
+    torch.cuda.synchronize()
+    assert torch.equal(rec1, rec2)
+    assert torch.equal(a1, a2) and torch.equal(c1, c2) and torch.equal(e1, e2)
+    # a shape outside the fused kernels: prep_local declines, forward alone does everything
+    odd = HipBilinearOps()
+    assert odd.prep_local(xs[:, :d - 4].contiguous(), [w[:d - 4].contiguous()], b, pc) is False and odd._local_ws is None
+
+
+@pytest.mark.parametrize("b,d,k,G", [(512, 256, 256, 4), (256, 128, 64, 2)])
+def test_separable_row_blocks_equal_full_batch(dev, b, d, k, G):
+    """The separable critic (BASELINE configs[1]) on the sharded path's ops object: per-block records merged in block
+    order and per-block gradients summed against the rounded oracle of the full batch."""
+    from mutual_info_img_txt.distributed import HipSeparableOps
+    gen = torch.Generator().manual_seed(b + k)
+    x = torch.randn(b, d, generator=gen)
+    y = torch.randn(b, d, generator=gen)
+    wg = torch.randn(d, k, generator=gen) * (0.5 / math.sqrt(d))
+    wh = torch.randn(d, k, generator=gen) * (0.5 / math.sqrt(d))
+    sid = torch.arange(b)
+    sid[3] = sid[b - 5]
+    ops = HipSeparableOps()
+    xd, yd, gd, hd, sd = (t.to(dev) for t in (x, y, wg, wh, sid))
+    br = b // G
+    recs, saved = [], []
+    for g in range(G):
+        rec, sv = ops.forward(xd[g * br:(g + 1) * br].contiguous(), yd, [gd, hd], sd[g * br:(g + 1) * br].contiguous(), sd,
+                              g * br, 1, 1, True)
+        recs.append(rec)
+        saved.append(sv)
+    loss, stats = ops.merge(torch.stack(recs), b, 1)
+    go = torch.ones(1, device=dev)
+    gx, gy, gg, gh = torch.empty_like(xd), torch.zeros_like(yd), torch.zeros_like(gd), torch.zeros_like(hd)
+    for g in range(G):
+        a, c, (e, f) = ops.backward(saved[g], stats, go)
+        gx[g * br:(g + 1) * br] = a
+        gy += c
+        gg += e
+        gh += f
+    o = orc.separable_step_rounded(x, y, wg, wh, sid, "infonce")
+    assert abs(float(loss) - float(o["loss"])) < 2e-3 * float(o["scores"].abs().max())
+    for name, got, ref in (("dx", gx, o["dx"]), ("dy", gy, o["dy"]), ("dwg", gg, o["dwg"]), ("dwh", gh, o["dwh"])):
+        assert _rel(got.cpu(), ref) < 1e-2, name
+
+
 def test_flash_unaligned_row_offset_and_flag_values(dev):
     """A row block whose offset is NOT a multiple of 32: the diagonal of the pair matrix then cuts through the 32 x 32
     tiles instead of lying on their main diagonals, the tile flags must say "general" (2) there and the kernel must take
