@@ -117,6 +117,82 @@ __device__ __forceinline__ unsigned ballot_to_lanes(unsigned word, unsigned long
   return word;
 }
 
+// ---- epilogue of a pass (shared by the register-staged and the LDS-DMA kernel) --------------------------------------
+// Straight-line, no SGPR hand-overs.  (The first version branched per accumulator register -- `s += pos ? z * w3 : 0`
+// became an exec-masked block with its own LDS read and wait -- and built the column words from 128 ballots moved into
+// lanes with 256 v_writelane: ~3000 instructions and 128 exposed LDS latencies per row of the tile and pass.)
+//   s      : zc = max(z, 0); s += zc * w3          (w3 of the lane's 64 hidden units: 16 ds_read_b128 issued up front)
+//   bitsP  : bit = (zc != 0) = sign of (0 - bits(zc)), shifted into the word with v_alignbit (registers taken from the
+//            last to the first, so that register r ends at bit 16 (a & 1) + r)
+//   bitsN  : the 32 x 32 bit transpose of the bitsP words of the 32 columns of a half-wave (5 butterfly stages over
+//            ds_swizzle: stage j exchanges bit-index bit j with lane-index bit j), i.e. lane c ends with the column word
+//            of the hidden unit of ITS bit position q = c -- instead of a ballot per accumulator register.
+struct BitTransposeLane {
+  unsigned msel[5];  // bits kept from the lane's own word at stage j = 16 >> s
+  unsigned amt[5];   // right-rotation of the partner's word
+};
+__device__ __forceinline__ BitTransposeLane bit_transpose_lane(int c) {
+  BitTransposeLane k;
+  constexpr unsigned low[5] = {0x0000FFFFu, 0x00FF00FFu, 0x0F0F0F0Fu, 0x33333333u, 0x55555555u};
+#pragma unroll
+  for (int s = 0; s < 5; ++s) {
+    const int j = 16 >> s;
+    const bool lo = (c & j) == 0;
+    k.msel[s] = lo ? low[s] : ~low[s];
+    k.amt[s] = lo ? 32 - j : j;
+  }
+  return k;
+}
+template <int S>
+__device__ __forceinline__ unsigned bit_transpose_stage(unsigned w, const BitTransposeLane& k) {
+  constexpr int J = 16 >> S;
+  const unsigned other = (unsigned)__builtin_amdgcn_ds_swizzle((int)w, (J << 10) | 0x1f);  // lane ^ J within 32 lanes
+  const unsigned rot = __builtin_amdgcn_alignbit(other, other, k.amt[S]);
+  return (w & k.msel[S]) | (rot & ~k.msel[S]);
+}
+__device__ __forceinline__ unsigned bit_transpose32(unsigned w, const BitTransposeLane& k) {
+  w = bit_transpose_stage<0>(w, k);
+  w = bit_transpose_stage<1>(w, k);
+  w = bit_transpose_stage<2>(w, k);
+  w = bit_transpose_stage<3>(w, k);
+  return bit_transpose_stage<4>(w, k);
+}
+
+// acc[a][r] of ONE row t of the tile: hidden unit 32 a + (r & 3) + 8 (r >> 2) + 4 h of the wave's 128, column c.
+// Returns this lane's partial score; stores the row's bitsP word and the two bitsN words of the lane when `bits`.
+__device__ __forceinline__ float fwd_epilogue_row(const f32x16& a0, const f32x16& a1, const f32x16& a2, const f32x16& a3,
+                                                  const float* w3w /* LDS: the wave's 128 values of w3 */, int h, int c,
+                                                  bool bits, bool row_ok, bool col_ok, unsigned long long* bitsP_word,
+                                                  unsigned* bitsN_row /* + hidden unit */, const BitTransposeLane& k) {
+  f32x4 w3v[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) w3v[a][g] = *reinterpret_cast<const f32x4*>(w3w + a * 32 + 8 * g + 4 * h);
+  const f32x16* acc[4] = {&a0, &a1, &a2, &a3};
+  float s0 = 0.0f, s1 = 0.0f;
+  unsigned pw[2] = {0u, 0u};
+#pragma unroll
+  for (int a = 3; a >= 0; --a)
+#pragma unroll
+    for (int r = 15; r >= 0; --r) {
+      const float zc = fmaxf((*acc[a])[r], 0.0f);
+      if (r & 1) s1 = fmaf(zc, w3v[a][r >> 2][r & 3], s1);
+      else s0 = fmaf(zc, w3v[a][r >> 2][r & 3], s0);
+      pw[a >> 1] = __builtin_amdgcn_alignbit(pw[a >> 1], 0u - __builtin_bit_cast(unsigned, zc), 31);
+    }
+  if (bits) {
+    if (row_ok && col_ok) *bitsP_word = ((unsigned long long)pw[1] << 32) | pw[0];
+    const int nn = ((c & 15) & 3) + 8 * ((c & 15) >> 2) + 4 * h;
+#pragma unroll
+    for (int w = 0; w < 2; ++w) {
+      const unsigned t = bit_transpose32(pw[w], k);
+      if (row_ok) bitsN_row[(2 * w + (c >> 4)) * 32 + nn] = t;
+    }
+  }
+  return s0 + s1;
+}
+
 template <typename OpT, int NWN>
 __global__ __launch_bounds__(256 * NWN, 2) /* 2 waves per SIMD: <= 256 registers */ void concat_fwd_kernel(const float* __restrict__ U, const float* __restrict__ V,
                                                                const OpT* __restrict__ W2, const float* __restrict__ b2,
@@ -136,6 +212,7 @@ __global__ __launch_bounds__(256 * NWN, 2) /* 2 waves per SIMD: <= 256 registers
   const int wave = tid >> 6, lane = tid & 63;
   const int wn = wave >> 2, wp = wave & 3;
   const int c = lane & 31, h = lane >> 5;
+  const BitTransposeLane btl = bit_transpose_lane(c);
   const int64_t i0 = (int64_t)blockIdx.y * kFwdTI, j0 = (int64_t)blockIdx.x * kFwdTJ;
   const int n_pass = H2 / NP;
   const int n_kt = H1 / KT;
@@ -287,37 +364,18 @@ __global__ __launch_bounds__(256 * NWN, 2) /* 2 waves per SIMD: <= 256 registers
       __syncthreads();
     }
 
-    // ---- epilogue of the pass: relu, dot with w3, sign bits ------------------------------------------------------
+    // ---- epilogue of the pass: relu, dot with w3, sign bits (fwd_epilogue_row) ----------------------------------------
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
       const int64_t li = i0 + 2 * wp + t;   // local image row of this pair tile
       const int64_t gj = j0 + c;            // text column of this lane
       const int pw = pass * NWN + wn;       // 128-wide hidden-unit group
-      float s = 0.0f;
-      unsigned long long pbits = 0ull;
-#pragma unroll
-      for (int a = 0; a < 4; ++a) {
-        unsigned nword = 0u;  // lanes 0..31 collect the 32-column sign words of hidden units 32a + lane
-        static_for<16>([&](auto rc) {
-          constexpr int r = decltype(rc)::value;
-          const int nl = wn * 128 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-          const float z = acc[a][t][r];
-          const bool pos = z > 0.0f;
-          s += pos ? z * sm.w3[nl] : 0.0f;
-          if (bitsP) {
-            pbits |= (unsigned long long)(pos ? 1u : 0u) << (16 * a + r);
-            const unsigned long long bal = __ballot(pos);
-            nword = ballot_to_lanes<LANE_OF_REG(r)>(nword, bal);
-          }
-        });
-        if (bitsP && lane < 32 && li < b_rows)
-          bitsN[(li * JB + blockIdx.x) * H2 + pw * 128 + a * 32 + lane] = nword;
-      }
-      if (bitsP && li < b_rows && gj < b) {
-        const int64_t wpp = H2 / 64;  // 64-bit words per pair
-        bitsP[bitsp_index(li, gj, h, pw, (b + 31) / 32, (int)(wpp / 2))] = pbits;
-      }
-      s_total[t] += s;
+      const bool row_ok = li < b_rows, col_ok = gj < b;
+      const int64_t lic = row_ok ? li : 0, gjc = col_ok ? gj : 0;
+      s_total[t] += fwd_epilogue_row(acc[0][t], acc[1][t], acc[2][t], acc[3][t], &sm.w3[wn * 128], h, c, bitsP != nullptr,
+                                     row_ok, col_ok,
+                                     bitsP + bitsp_index(lic, gjc, h, pw, (b + 31) / 32, (int)(H2 / 128)),
+                                     bitsN + (lic * JB + blockIdx.x) * H2 + pw * 128, btl);
     }
   }
 

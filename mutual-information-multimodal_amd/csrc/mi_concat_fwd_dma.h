@@ -46,6 +46,7 @@ __global__ __launch_bounds__(256 * NWN, 2) void concat_fwd_dma_kernel(
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const int wn = wave >> 2, wp = wave & 3;
   const int c = lane & 31, h = lane >> 5;
+  const BitTransposeLane btl = bit_transpose_lane(c);
   // XCD-aware tile order: XCD e owns the column tiles jt = e + 8 m and takes them one at a time, sweeping all row tiles
   // under each.  The workgroups resident on an XCD then share ONE V tile (128 KB) and differ in their U tiles (32 KB
   // each): per workgroup only its U tile is new to the L2.  (Cycling through the XCD's 16 column tiles first kept 2 MB
@@ -183,37 +184,18 @@ __global__ __launch_bounds__(256 * NWN, 2) void concat_fwd_dma_kernel(
       __syncthreads();  // vmcnt(0) + barrier: tile kt+1 landed, buffer `buf` free for tile kt+2
     }
 
-    // ---- epilogue of the pass: relu, dot with w3, sign bits ------------------------------------------------------
+    // ---- epilogue of the pass: relu, dot with w3, sign bits (fwd_epilogue_row, mi_concat_fwd.h) ------------------------
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
       const int64_t li = i0 + 2 * wp + t;
       const int64_t gj = j0 + c;
       const int pw = pass * NWN + wn;
-      float s = 0.0f;
-      unsigned long long pbits = 0ull;
-#pragma unroll
-      for (int a = 0; a < 4; ++a) {
-        unsigned nword = 0u;
-        static_for<16>([&](auto rc) {
-          constexpr int r = decltype(rc)::value;
-          const int nl = wn * 128 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-          const float z = acc[a][t][r];
-          const bool pos = z > 0.0f;
-          s += pos ? z * w3s[nl] : 0.0f;
-          if (bitsP) {
-            pbits |= (unsigned long long)(pos ? 1u : 0u) << (16 * a + r);
-            const unsigned long long bal = __ballot(pos);
-            nword = ballot_to_lanes<LANE_OF_REG(r)>(nword, bal);
-          }
-        });
-        if (bitsP && lane < 32 && li < b_rows)
-          bitsN[(li * JB + jt) * H2 + pw * 128 + a * 32 + lane] = nword;
-      }
-      if (bitsP && li < b_rows && gj < b) {
-        const int64_t wpp = H2 / 64;
-        bitsP[bitsp_index(li, gj, h, pw, (b + 31) / 32, (int)(wpp / 2))] = pbits;
-      }
-      s_total[t] += s;
+      const bool row_ok = li < b_rows, col_ok = gj < b;
+      const int64_t lic = row_ok ? li : 0, gjc = col_ok ? gj : 0;
+      s_total[t] += fwd_epilogue_row(acc[0][t], acc[1][t], acc[2][t], acc[3][t], w3s + wn * 128, h, c, bitsP != nullptr,
+                                     row_ok, col_ok,
+                                     bitsP + bitsp_index(lic, gjc, h, pw, (b + 31) / 32, (int)(H2 / 128)),
+                                     bitsN + (lic * JB + jt) * H2 + pw * 128, btl);
     }
   }
 
