@@ -158,6 +158,20 @@ int mi_bilinear_bwd(const float* x, const float* y, const float* w, const int64_
 int mi_bilinear_prep_local(const float* x, const float* w, int64_t b_rows, int64_t b, int64_t d_img, int64_t d_txt,
                            int precision, void* workspace, size_t workspace_bytes, void* stream);
 
+/* Sharded batches without the finalize and merge launches: mi_bilinear_fwd(..., need_grad | 8, ...) leaves one 16-byte
+ * record per wave of the fused kernel in the workspace and writes no loss / stats / partials_out;
+ * mi_bilinear_raw_records returns their count (0: the shape does not take this path) and, through offset_bytes, where
+ * they start in the workspace.  All-gather that region from every rank (rank order) and call mi_bilinear_bwd_records on
+ * the forward's workspace: its first launch merges all n_records records in the given order on every workgroup
+ * (bit-identical loss / stats on every rank; n_pos = the global batch), then computes the gradients as mi_bilinear_bwd. */
+size_t mi_bilinear_raw_records(int64_t b_rows, int64_t b, int64_t d_img, int64_t d_txt, int precision,
+                               size_t* offset_bytes);
+int mi_bilinear_bwd_records(const float* x, const float* y, const float* w, const int64_t* sid_rows,
+                            const int64_t* sid_cols, int64_t b_rows, int64_t b, int64_t row_offset, int64_t d_img,
+                            int64_t d_txt, int precision, int estimator, const float* records, int64_t n_records,
+                            int64_t n_pos, const float* grad_out, float* loss_out, mi_stats* stats_out, float* grad_x,
+                            float* grad_y, float* grad_w, void* workspace, size_t workspace_bytes, void* stream);
+
 /* fp8 mode (MI_PREC_FP8) on a sharded batch: the per-tensor scales must be the whole batch's.  The forward's preparation
  * in three stages around the caller's two MAX all-reduces of amax_io (4 floats on the device: x, y, w, T):
  *   stage 0 -> amax_io[0..2] | all-reduce MAX | stage 1 -> amax_io[3] | all-reduce MAX | stage 2,

@@ -212,6 +212,8 @@ struct TailMerge {
   float* loss_out;
   mi_stats* stats_out;
   float* partials_out;
+  const float* records = nullptr;  // sharded: the raw records gathered from every rank (rank order), else the workspace's
+  int64_t n_records = 0, n_pos = 0;
 };
 static int bilinear_tail(int64_t br, int64_t b, int64_t row_offset, int64_t dx, int64_t dy, const mi_stats* stats,
                          const float* grad_out, float* grad_x, float* grad_y, float* grad_w, const BilinearPlan& p,
@@ -224,9 +226,9 @@ static int bilinear_tail(int64_t br, int64_t b, int64_t row_offset, int64_t dx, 
   ta.stats = stats;
   ta.grad_out = grad_out;
   if (merge) {
-    ta.merge_rec = p.fl_rec[0];
-    ta.n_merge = p.fl.n_rec[0];
-    ta.n_pos = b;
+    ta.merge_rec = merge->records ? (const Partial*)merge->records : p.fl_rec[0];
+    ta.n_merge = merge->records ? merge->n_records : p.fl.n_rec[0];
+    ta.n_pos = merge->records ? merge->n_pos : b;
     ta.estimator = merge->estimator;
     ta.loss_out = merge->loss_out;
     ta.stats_out = merge->stats_out;
@@ -259,6 +261,9 @@ static int bilinear_fwd_fast(const float* x, const float* y, const float* w, con
                             "bilinear score+LSE");
       if (rc) return rc;
     }
+    // need_grad bit 3: the caller gathers the RAW per-wave records (mi_bilinear_raw_records) from every rank and hands
+    // them to mi_bilinear_bwd_records, whose first launch merges them: no finalize launch, nothing written to loss / stats
+    if ((need_grad & 8) && p.tail) return MI_OK;
     return launch_finalize(p.fl_rec[0], p.fl.n_rec[0], b, estimator, loss_out, stats, partials_out, st);
   }
   const int x3 = p.x3;
@@ -633,6 +638,49 @@ int mi_bilinear_bwd(const float* x, const float* y, const float* w, const int64_
                                              grad_out, grad_x, grad_y, grad_w, p, st);
   return bilinear_bwd_impl<float, float>(x, y, w, sid_rows, sid_cols, b_rows, b, row_offset, d_img, d_txt, stats,
                                          grad_out, grad_x, grad_y, grad_w, p, st);
+}
+
+/* Sharded batches without the finalize and merge launches.  The fused kernel leaves one 16-byte record per wave in the
+ * workspace; mi_bilinear_raw_records says where (byte offset) and how many.  A rank runs mi_bilinear_fwd(need_grad | 8)
+ * (no finalize: loss / stats / partials_out untouched), all-gathers that region from every rank (rank order) and calls
+ * mi_bilinear_bwd_records, whose first launch merges ALL records in the gathered order on every workgroup (bit-identical
+ * statistics and loss on every rank), writes loss / stats and goes on with the backward's tail.  0 records = the shape
+ * does not take this path (use mi_bilinear_fwd / mi_merge_partials / mi_bilinear_bwd). */
+size_t mi_bilinear_raw_records(int64_t b_rows, int64_t b, int64_t d_img, int64_t d_txt, int precision,
+                               size_t* offset_bytes) {
+  if (b_rows <= 0 || b <= 0 || d_img <= 0 || d_txt <= 0) return 0;
+  char* fake = reinterpret_cast<char*>(uintptr_t(1) << 20);  // only pointer differences are used
+  Workspace ws(fake, ~size_t(0) >> 1);
+  BilinearPlan p = plan_bilinear(ws, b_rows, b, d_img, d_txt, precision);
+  if (!(fast_ok(b_rows, b, d_img, d_txt, precision, true) && p.fl.ok && p.tail)) return 0;
+  if (offset_bytes) *offset_bytes = (size_t)(reinterpret_cast<char*>(p.fl_rec[0]) - fake);
+  return (size_t)p.fl.n_rec[0];
+}
+
+int mi_bilinear_bwd_records(const float* x, const float* y, const float* w, const int64_t* sid_rows,
+                            const int64_t* sid_cols, int64_t b_rows, int64_t b, int64_t row_offset, int64_t d_img,
+                            int64_t d_txt, int precision, int estimator, const float* records, int64_t n_records,
+                            int64_t n_pos, const float* grad_out, float* loss_out, mi_stats* stats_out, float* grad_x,
+                            float* grad_y, float* grad_w, void* workspace, size_t workspace_bytes, void* stream) {
+  MI_CHECK_ARG(x && y && w && sid_rows && sid_cols && records && stats_out && grad_x && grad_y && grad_w && workspace,
+               "mi_bilinear_bwd_records: null pointer");
+  MI_CHECK_ARG(n_records > 0 && n_pos > 0, "mi_bilinear_bwd_records: n_records and n_pos must be positive");
+  MI_CHECK_ARG(estimator == MI_DV || estimator == MI_INFONCE, "mi_bilinear_bwd_records: unknown estimator %d", estimator);
+  int rc = check_common("mi_bilinear_bwd_records", b_rows, b, row_offset, d_img, d_txt, precision);
+  if (rc) return rc;
+  Workspace ws(workspace, workspace_bytes);
+  BilinearPlan p = plan_bilinear(ws, b_rows, b, d_img, d_txt, precision);
+  if (!ws.ok()) {
+    set_error("mi_bilinear_bwd_records: workspace too small (%zu < %zu)", workspace_bytes, ws.off);
+    return MI_EWORKSPACE;
+  }
+  if (!(fast_ok(b_rows, b, d_img, d_txt, precision, true) && p.fl.ok && p.tail)) {
+    set_error("mi_bilinear_bwd_records: shape / precision outside the fused kernels (mi_bilinear_raw_records returns 0)");
+    return MI_ESHAPE;
+  }
+  TailMerge tm{estimator, loss_out, stats_out, nullptr, records, n_records, n_pos};
+  return bilinear_tail(b_rows, b, row_offset, d_img, d_txt, nullptr, grad_out, grad_x, grad_y, grad_w, p, &tm,
+                       (hipStream_t)stream);
 }
 
 /* Sharded batches: the part of the forward's preparation that depends on the rank's OWN rows only -- the bf16 copies of

@@ -61,6 +61,8 @@ SIGNATURES = {
     "mi_bilinear_workspace_bytes": (_SZ, [_I64, _I64, _I64, _I64, _I]),
     "mi_bilinear_fwd": (c_int, [_P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I, _I, _I, _P, _P, _P, _P, _P, _SZ, _P]),
     "mi_bilinear_bwd": (c_int, [_P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I, _P, _P, _P, _P, _P, _P, _SZ, _I, _P]),
+    "mi_bilinear_raw_records": (_SZ, [_I64, _I64, _I64, _I64, _I, _P]),
+    "mi_bilinear_bwd_records": (c_int, [_P] * 5 + [_I64] * 5 + [_I, _I, _P, _I64, _I64] + [_P] * 7 + [_SZ, _P]),
     "mi_bilinear_prep_local": (c_int, [_P, _P, _I64, _I64, _I64, _I64, _I, _P, _SZ, _P]),
     "mi_bilinear_fp8_stage": (c_int, [_P, _P, _P, _I64, _I64, _I64, _I64, _I, _P, _P, _SZ, _P]),
     "mi_bilinear_step": (c_int, [_P, _P, _P, _P, _I64, _I64, _I64, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _SZ, _P]),

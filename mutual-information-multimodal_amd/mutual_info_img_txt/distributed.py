@@ -15,6 +15,7 @@ The local compute is an ``ops`` object.  The product default runs the HIP kernel
 """
 from __future__ import annotations
 
+import ctypes
 import os
 from typing import List, Optional, Sequence
 
@@ -92,6 +93,51 @@ class HipBilinearOps:
                                        ws.data_ptr(),
                                        ws.numel())
         return record, (x, y_all, w, sid_rows, sid_all, row_offset, precision, ws)
+
+    def forward_raw(self, x, y_all, params, sid_rows, sid_all, row_offset, estimator, precision):
+        """Forward WITHOUT the finalize launch (mi_bilinear_fwd, need_grad bit 3): returns the fused kernel's per-wave
+        records ([n, 4] float32, a view of the workspace) for the caller to all-gather, or None where the shape does not take
+        that path.  `merge_backward` then merges the gathered records inside the backward's first launch."""
+        lib = _hip.load()
+        (w,) = params
+        br, dx = x.shape
+        b, dy = y_all.shape
+        off = ctypes.c_size_t(0)
+        n = lib.mi_bilinear_raw_records(br, b, dx, dy, precision, ctypes.byref(off))
+        if n == 0:
+            return None
+        dev = x.device
+        flags = 1 | 8
+        if self._local_ws is not None:
+            ws, self._local_ws = self._local_ws, None
+            flags |= 4
+        else:
+            ws = _hip.workspace(lib.mi_bilinear_workspace_bytes(br, b, dx, dy, precision), dev)
+        stats = _hip.new_stats(dev)  # (untouched by this call; the C ABI wants a valid pointer)
+        _hip.call("mi_bilinear_fwd", dev, x.data_ptr(), y_all.data_ptr(), w.data_ptr(), sid_rows.data_ptr(),
+                  sid_all.data_ptr(), br, b, row_offset, dx, dy, estimator, precision, flags, None, stats.data_ptr(), None,
+                  None, ws.data_ptr(), ws.numel())
+        records = ws[off.value:off.value + 16 * n].view(torch.float32).view(n, 4)
+        return records, (x, y_all, w, sid_rows, sid_all, row_offset, precision, ws)
+
+    def merge_backward(self, saved, records_all, n_pos, estimator, grad_out, out=None):
+        """mi_bilinear_bwd_records: merge of the gathered raw records (rank order), loss, statistics and all gradients in
+        the backward's two launches."""
+        x, y_all, w, sid_rows, sid_all, row_offset, precision, ws = saved
+        br, dx = x.shape
+        b, dy = y_all.shape
+        dev = x.device
+        if out is None:
+            gx, gy, gw = torch.empty_like(x), torch.empty_like(y_all), torch.empty_like(w)
+        else:
+            gx, gy, (gw,) = out
+        stats = _hip.new_stats(dev)
+        loss = torch.empty(1, dtype=torch.float32, device=dev)
+        _hip.call("mi_bilinear_bwd_records", dev, x.data_ptr(), y_all.data_ptr(), w.data_ptr(), sid_rows.data_ptr(),
+                  sid_all.data_ptr(), br, b, row_offset, dx, dy, precision, estimator, records_all.data_ptr(),
+                  records_all.shape[0], n_pos, grad_out.data_ptr(), loss.data_ptr(), stats.data_ptr(), gx.data_ptr(),
+                  gy.data_ptr(), gw.data_ptr(), ws.data_ptr(), ws.numel())
+        return loss, stats, gx, gy, [gw]
 
     def merge(self, records, n_pos, estimator):
         lib = _hip.load()
@@ -358,6 +404,10 @@ class GlobalBatchGraphStep:
         graph 1: rest of the local forward -> partial record | all-gather records |
         graph 2: rank-ordered merge + local backward | reduce-scatter dY, all-reduce d(params)
 
+    Bilinear critic on the fused kernels ("raw-record mode"): graph 1 ends with the fused B x B kernel (no finalize
+    launch), the all-gather moves every rank's per-wave records (16 bytes each, a few KB per rank) and the first launch
+    of graph 2 merges ALL of them in the gathered order on every workgroup -- no merge launch either.
+
     Why: at global batch 4096 a rank's kernels take tens of microseconds, and launching them one by one from Python
     (plus an autograd graph) costs several times that.  The graphs hold exactly the C-ABI calls of
     ``GlobalBatchCriticFn``; no collective is captured (RCCL calls stay ordinary stream work between two replays).
@@ -394,6 +444,11 @@ class GlobalBatchGraphStep:
             self.grad_y_partial = torch.empty_like(self.y_all)
             self._out = (self.grad_x, self.grad_y_partial, self.grad_params)
         self.graph_fwd = self.graph_bwd = self.graph_local = self.graph_full = None
+        # raw-record mode (ops.forward_raw / merge_backward): the per-wave records of every rank are gathered and merged
+        # inside the backward's first launch -- no finalize and no merge launch.  MI_DIST_NO_RAW=1: A/B switch.
+        self._raw = (hasattr(self.ops, "forward_raw") and self.prec != _hip.MI_PREC_FP8
+                     and not os.environ.get("MI_DIST_NO_RAW"))
+        self.records_raw = None
         # MI_DIST_NO_OVERLAP=1: A/B switch of the measurements in profiles/README.md (the local part then runs inside forward)
         self._has_local = hasattr(self.ops, "prep_local") and not os.environ.get("MI_DIST_NO_OVERLAP")
         self._gather_inputs(local=False)
@@ -410,6 +465,7 @@ class GlobalBatchGraphStep:
         with torch.cuda.stream(side):
             self._prep_local()
             self._forward()
+            self._gather_records()
             self._merge_backward()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
@@ -440,7 +496,7 @@ class GlobalBatchGraphStep:
         with torch.cuda.graph(self.graph_fwd, pool=pool):
             self._forward()
         # the record gathered from every rank must exist before the second capture reads it
-        dist.all_gather_into_tensor(self.records, self.record.reshape(1, -1), group=self.group)
+        self._gather_records()
         self.graph_bwd = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph_bwd, pool=pool):
             self._merge_backward()
@@ -462,12 +518,36 @@ class GlobalBatchGraphStep:
             w.wait()
 
     def _forward(self):
+        if self._raw:
+            got = self.ops.forward_raw(self.x, self.y_all, self.params, self.sid, self.sid_all,
+                                       self.rank * self.x.shape[0], self.est, self.prec)
+            if got is not None:
+                self.record, self.saved = got  # [n, 4]: gathered as it is
+                if self.records_raw is None:
+                    self.records_raw = torch.empty((self.world * self.record.shape[0], 4), dtype=self.record.dtype,
+                                                   device=self.record.device)
+                return
+            self._raw = False  # the shape does not take that path: the record protocol below, from now on
         if self.prec == _hip.MI_PREC_FP8:  # (two tiny MAX all-reduces inside: this section is never captured in that mode)
             fp8_global_scales(self.ops, self.x, self.y_all, self.params, self.group)
         self.record, self.saved = self.ops.forward(self.x, self.y_all, self.params, self.sid, self.sid_all,
                                                    self.rank * self.x.shape[0], self.est, self.prec, True)
 
+    def _gather_records(self):
+        if self._raw:
+            dist.all_gather_into_tensor(self.records_raw, self.record, group=self.group)
+        else:
+            dist.all_gather_into_tensor(self.records, self.record.reshape(1, -1).to(self.records.dtype), group=self.group)
+
     def _merge_backward(self):
+        if self._raw:
+            self.loss, self.stats, gx, gy, gp = self.ops.merge_backward(
+                self.saved, self.records_raw, self.world * self.x.shape[0], self.est, self.grad_out, out=self._out)
+            if self._out is None:
+                self.grad_x, self.grad_y_partial = gx, gy
+                for v, g in zip(self.grad_params, gp):
+                    v.copy_(g)
+            return
         self.loss, self.stats = self.ops.merge(self.records, self.world * self.x.shape[0], self.est)
         if self._out is not None:
             self.ops.backward(self.saved, self.stats, self.grad_out, out=self._out)
@@ -484,7 +564,7 @@ class GlobalBatchGraphStep:
     def _whole_step(self):
         self._gather_inputs()
         self._forward()
-        dist.all_gather_into_tensor(self.records, self.record.reshape(1, -1), group=self.group)
+        self._gather_records()
         self._merge_backward()
         if self._reduce_scatter_out is not None:
             dist.reduce_scatter_tensor(self._reduce_scatter_out, self.grad_y_partial, group=self.group)
@@ -504,7 +584,7 @@ class GlobalBatchGraphStep:
             return self.step_eager()
         self._gather_inputs()
         self.graph_fwd.replay()
-        dist.all_gather_into_tensor(self.records, self.record.reshape(1, -1), group=self.group)
+        self._gather_records()
         self.graph_bwd.replay()
         self._exchange_gradients()
         return self.loss
@@ -512,7 +592,7 @@ class GlobalBatchGraphStep:
     def step_eager(self):
         self._gather_inputs()
         self._forward()
-        dist.all_gather_into_tensor(self.records, self.record.reshape(1, -1).to(self.records.dtype), group=self.group)
+        self._gather_records()
         self._merge_backward()
         self._exchange_gradients()
         return self.loss

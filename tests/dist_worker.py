@@ -279,3 +279,58 @@ def run_variant(rank, world, port, b_local, d, estimator, out_dir, variant, stag
     torch.save(out, os.path.join(out_dir, f"rank{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
+
+
+class OracleRawBilinearOps(OracleBilinearOps):
+    """The raw-record protocol of HipBilinearOps (forward_raw / merge_backward): a rank hands back SEVERAL records (one per
+    column third here; the product: one per wave of the fused kernel), all ranks' records are gathered in rank order and
+    merged inside the backward."""
+
+    def __init__(self):
+        self.calls = []
+
+    def forward_raw(self, x, y_all, params, sid_rows, sid_all, row_offset, estimator, precision):
+        (w,) = params
+        self.calls.append("forward_raw")
+        s = (x @ w) @ y_all.t()
+        br, b = s.shape
+        diag = (torch.arange(br)[:, None] + row_offset) == torch.arange(b)[None, :]
+        neg = (~diag) & (sid_rows[:, None] != sid_all[None, :])
+        recs = []
+        for cols in torch.arange(b).chunk(3):
+            sn, sd = s[:, cols][neg[:, cols]], s[:, cols][diag[:, cols]]
+            m = sn.max() if sn.numel() else torch.tensor(float("-inf"), dtype=s.dtype)
+            ssum = torch.exp(sn - m).sum() if sn.numel() else torch.tensor(0.0, dtype=s.dtype)
+            recs.append(torch.stack([m, ssum, sd.sum(), torch.tensor(float(sn.numel()), dtype=s.dtype)]))
+        return torch.stack(recs).contiguous(), (x, y_all, w, s, diag, neg)
+
+    def merge_backward(self, saved, records_all, n_pos, estimator, grad_out, out=None):
+        self.calls.append(f"merge_backward:{records_all.shape[0]}")
+        m = records_all[:, 0].max()
+        ssum = (records_all[:, 1] * torch.exp(records_all[:, 0] - m)).sum()
+        lse = m + torch.log(ssum)
+        loss = lse - records_all[:, 2].sum() / n_pos - (torch.log(records_all[:, 3].sum()) if estimator == 0 else 0.0)
+        stats = torch.stack([lse, torch.tensor(float(n_pos), dtype=lse.dtype)])
+        gx, gy, gp = OracleBilinearOps.backward(self, saved, stats, grad_out)
+        return loss.reshape(1), stats, gx, gy, gp
+
+
+def run_raw(rank, world, port, b_local, d, estimator, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from mutual_info_img_txt.distributed import GlobalBatchGraphStep
+    from oracle import mi_oracle as orc
+    b = b_local * world
+    x, y, sid, _ = orc.synthetic_case(b, d, d, h1=8, h2=8, salt=21, dup=True, dtype=torch.float64)
+    w = orc.hash_uniform((d, d), 99, torch.float64)
+    codes = torch.from_numpy(orc.sid_to_int(sid))
+    sl = slice(rank * b_local, (rank + 1) * b_local)
+    ops = OracleRawBilinearOps()
+    st = GlobalBatchGraphStep(x[sl].contiguous(), y[sl].contiguous(), codes[sl].contiguous(), [w.clone()], estimator, "f32",
+                              critic="bilinear", group=dist.group.WORLD, ops=ops, capture=False)
+    st.step()
+    loss = st.step()
+    torch.save({"loss": loss.detach().reshape(-1), "dx": st.grad_x, "dy": st.grad_y, "dparams": [g.clone() for g in st.grad_params],
+                "calls": list(ops.calls)}, os.path.join(out_dir, f"rank{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()

@@ -120,3 +120,26 @@ def test_split_forward_and_separable_two_ranks(tmp_path, variant, staged):
     assert torch.equal(outs[0]["loss"], outs[1]["loss"])
     for a, c in zip(outs[0]["dparams"], outs[1]["dparams"]):
         assert torch.equal(a, c)
+
+
+@pytest.mark.parametrize("estimator", ["dv", "infonce"])
+def test_raw_record_protocol_two_ranks(tmp_path, estimator):
+    """The staged step's raw-record mode (ops.forward_raw / merge_backward: what the bilinear critic's fused kernels use on
+    a sharded batch -- no finalize and no merge launch): every rank's several records are gathered in rank order and
+    merged inside the backward.  Oracle-backed ops, three records per rank; against the single-process oracle."""
+    world, b_local, d = 2, 6, 5
+    mp.spawn(dist_worker.run_raw, args=(world, _free_port(), b_local, d, estimator, str(tmp_path)), nprocs=world, join=True)
+    b = world * b_local
+    x, y, sid, _ = orc.synthetic_case(b, d, d, h1=8, h2=8, salt=21, dup=True, dtype=torch.float64)
+    w = orc.hash_uniform((d, d), 99, torch.float64)
+    ref = orc.matrix_step(lambda a, c, ww: orc.bilinear_scores(a, c, ww), [x, y, w], sid, estimator)
+    outs = [torch.load(os.path.join(tmp_path, f"rank{r}.pt"), weights_only=True) for r in range(world)]
+    for r, o in enumerate(outs):
+        sl = slice(r * b_local, (r + 1) * b_local)
+        # (DV: the reference takes log N_neg in float32, mi_critics.py:10)
+        np.testing.assert_allclose(o["loss"].numpy().reshape(-1), ref["loss"].numpy().reshape(-1), rtol=1e-6, atol=1e-6)
+        np.testing.assert_allclose(o["dx"].numpy(), ref["grads"][0][sl].numpy(), rtol=1e-8, atol=1e-12)
+        np.testing.assert_allclose(o["dy"].numpy(), ref["grads"][1][sl].numpy(), rtol=1e-8, atol=1e-12)
+        np.testing.assert_allclose(o["dparams"][0].numpy(), ref["grads"][2].numpy(), rtol=1e-8, atol=1e-12)
+        assert o["calls"] == ["forward_raw", "merge_backward:6"] * 2, o["calls"]
+    assert torch.equal(outs[0]["loss"], outs[1]["loss"]) and torch.equal(outs[0]["dparams"][0], outs[1]["dparams"][0])

@@ -220,6 +220,69 @@ def test_split_forward_equals_the_one_call(dev, b, d, G, prec):
     assert odd.prep_local(xs[:, :d - 4].contiguous(), [w[:d - 4].contiguous()], b, pc) is False and odd._local_ws is None
 
 
+@pytest.mark.parametrize("b,d,G", [(1024, 512, 2), (512, 256, 4)])
+def test_raw_record_row_blocks_equal_record_path(dev, b, d, G):
+    """Sharded runs without the finalize / merge launches: mi_bilinear_fwd(need_grad | 8) per row block, the blocks' raw
+    per-wave records concatenated in block order (= the all-gather), mi_bilinear_bwd_records per block.  Every block gets
+    the same loss bits (same records, same merge order on every workgroup); loss and gradients agree with the record path
+    (finalize per block, mi_merge_partials, mi_bilinear_bwd) to fp32 rounding -- the merge ORDER differs -- and with the
+    rounded oracle at the usual 1e-2."""
+    from mutual_info_img_txt.distributed import HipBilinearOps
+    from mutual_info_img_txt import _hip
+    gen = torch.Generator().manual_seed(7 * b + G)
+    x = torch.randn(b, d, generator=gen)
+    y = torch.randn(b, d, generator=gen)
+    w = torch.randn(d, d, generator=gen) * (0.25 / math.sqrt(d))
+    sid = torch.arange(b)
+    sid[3] = sid[b - 5]
+    xd, yd, wd, sd = x.to(dev), y.to(dev), w.to(dev), sid.to(dev)
+    br = b // G
+    go = torch.ones(1, device=dev)
+    ops = HipBilinearOps()
+    raw, saved = [], []
+    for g in range(G):
+        got = ops.forward_raw(xd[g * br:(g + 1) * br].contiguous(), yd, [wd], sd[g * br:(g + 1) * br].contiguous(), sd, g * br, 1, 1)
+        assert got is not None
+        raw.append(got[0].clone())
+        saved.append(got[1])
+    records = torch.cat(raw).contiguous()
+    assert records.shape == (G * raw[0].shape[0], 4)
+    gx, gy, gw = torch.empty_like(xd), torch.zeros_like(yd), torch.zeros_like(wd)
+    losses = []
+    for g in range(G):
+        loss, stats, a, c, (e,) = ops.merge_backward(saved[g], records, b, 1, go)
+        losses.append(loss.clone())
+        gx[g * br:(g + 1) * br] = a
+        gy += c
+        gw += e
+    for l in losses[1:]:
+        assert torch.equal(l, losses[0])
+    assert _hip.stats_dict(stats)["n_neg"] == int(orc.negative_mask(sid).sum())
+    # the record path on the same blocks
+    recs, saved2 = [], []
+    for g in range(G):
+        rec, sv = ops.forward(xd[g * br:(g + 1) * br].contiguous(), yd, [wd], sd[g * br:(g + 1) * br].contiguous(), sd, g * br, 1, 1, True)
+        recs.append(rec)
+        saved2.append(sv)
+    loss2, stats2 = ops.merge(torch.stack(recs), b, 1)
+    hx, hy, hw = torch.empty_like(xd), torch.zeros_like(yd), torch.zeros_like(wd)
+    for g in range(G):
+        a, c, (e,) = ops.backward(saved2[g], stats2, go)
+        hx[g * br:(g + 1) * br] = a
+        hy += c
+        hw += e
+    assert abs(float(losses[0]) - float(loss2)) <= 2e-6 * max(1.0, abs(float(loss2)))
+    for name, got, ref in (("dx", gx, hx), ("dy", gy, hy), ("dw", gw, hw)):
+        assert _rel(got.cpu(), ref.cpu()) < 1e-4, name
+    o = orc.bilinear_step_rounded(x, y, w, sid, "infonce")
+    assert abs(float(losses[0]) - float(o["loss"])) < 2e-3 * float(o["scores"].abs().max())
+    for name, got, ref in (("dx", gx.cpu(), o["dx"]), ("dy", gy.cpu(), o["dy"]), ("dw", gw.cpu(), o["dw"])):
+        assert _rel(got, ref) < 1e-2, name
+    # a shape outside the fused kernels has no raw records
+    assert ops.forward_raw(xd[:br, :d - 4].contiguous(), yd[:, :d - 4].contiguous(), [wd[:d - 4, :d - 4].contiguous()],
+                           sd[:br].contiguous(), sd, 0, 1, 1) is None
+
+
 @pytest.mark.parametrize("b,d,k,G", [(512, 256, 256, 4), (256, 128, 64, 2)])
 def test_separable_row_blocks_equal_full_batch(dev, b, d, k, G):
     """The separable critic (BASELINE configs[1]) on the sharded path's ops object: per-block records merged in block
