@@ -146,6 +146,9 @@ def make_critic(kind, d_img, d_txt, seed, device):
     torch.manual_seed(seed)
     if kind == "bilinear":
         m = BilinearCritic(d_img, d_txt)
+    elif kind == "separable":
+        from mutual_info_img_txt.model import SeparableCritic
+        m = SeparableCritic(d_img, d_txt, d_txt)
     else:
         m = make_mlp(d_img + d_txt, [1024, 512])  # reference main_utils.py:77 with 2d inputs
     return m.to(device)
@@ -155,6 +158,8 @@ def algorithmic_flops(kind, b, d_img, d_txt, h1=1024, h2=512):
     """fwd + bwd, no recompute credit."""
     if kind == "bilinear":
         return 6.0 * b * b * d_txt + 6.0 * b * d_img * d_txt
+    if kind == "separable":  # two heads [d, d_proj = d_txt]
+        return 6.0 * b * b * d_txt + 6.0 * b * (d_img + d_txt) * d_txt
     return 6.0 * b * b * h1 * h2 + 6.0 * b * b * h2 + 12.0 * b * (d_img + d_txt) / 2 * h1
 
 
@@ -569,6 +574,24 @@ def main():
             del st4
         except Exception as e:
             out["fp8_mode"] = {"error": f"{type(e).__name__}: {e}"}
+        torch.cuda.empty_cache()
+    if not args.no_fp8 and args.critic == "bilinear" and world == 1:
+        # BASELINE configs[1]: InfoNCE separable critic S = (X Wg)(Y Wh)^T, 256-d, batch 256, bf16, one GPU
+        try:
+            bs, ds, ns = 256, 256, max(20, args.steps)
+            st5, el5, k5, _ = run("separable", ns, 5, precision="bf16", batch=bs, dim=ds)
+            ms5 = el5 / ns * 1e3
+            fl5 = algorithmic_flops("separable", bs, ds, ds)
+            out["separable_mode"] = {
+                "workload": f"BASELINE configs[1]: separable critic fwd+bwd (projections included), B={bs}, d={ds}, d_proj={ds}, bf16",
+                "value": round(bs / (ms5 * 1e-3), 1), "unit": "pairs/s", "ms_per_step": round(ms5, 4), "steps": ns,
+                "hip_graph": not st5.use_eager, "loss": st5.loss(),
+                "step_algorithmic_tflops": round(fl5 / (ms5 * 1e-3) / 1e12, 2),
+                "note": "0.3 GFLOP per step: launch- and latency-bound at this size, not a roofline case",
+                "kernels_us": {k: round(v["ms_avg"] * 1e3, 2) for k, v in sorted(k5.items(), key=lambda kv: -kv[1]["ms_total"])}}
+            del st5
+        except Exception as e:
+            out["separable_mode"] = {"error": f"{type(e).__name__}: {e}"}
         torch.cuda.empty_cache()
     if not args.no_secondary:
         other = "concat_mlp" if args.critic == "bilinear" else "bilinear"

@@ -44,8 +44,9 @@ class GraphedMiStep:
             self.params: List[torch.Tensor] = [critic.weight]
             self.prec = _hip.resolve_precision(precision, True, (self.b, self.dx, self.dy))  # "f32" -> bf16x3 here
         elif isinstance(critic, _model.SeparableCritic):
-            raise ValueError("SeparableCritic: project the embeddings first (its projections are ordinary modules) and "
-                             "build the step with critic=None on the projected widths")
+            self.kind = "separable"  # S = (X Wg)(Y Wh)^T: projections, B x B stage and gradients by mi_separable_fwd/bwd
+            self.params = [critic.wg, critic.wh]
+            self.k = int(critic.wg.shape[1])
         elif critic is None:
             if d_img != d_txt:
                 raise ValueError("critic=None is the separable form S = X Y^T: widths must agree")
@@ -72,6 +73,10 @@ class GraphedMiStep:
         self.grad_params = [torch.zeros_like(p) for p in self.params]
         if self.kind == "bilinear":
             nbytes = self.lib.mi_bilinear_workspace_bytes(self.b, self.b, self.dx, self.dy, self.prec)
+        elif self.kind == "separable":
+            if tuple(self.params[0].shape) != (self.dx, self.k) or tuple(self.params[1].shape) != (self.dy, self.k):
+                raise ValueError("projection shapes must be [d_img, d_proj] and [d_txt, d_proj]")
+            nbytes = self.lib.mi_separable_workspace_bytes(self.b, self.b, self.dx, self.dy, self.k, self.prec)
         else:
             self.h1, self.h2 = self.params[0].shape[0], self.params[2].shape[0]
             if self.params[0].shape[1] != self.dx + self.dy:
@@ -100,6 +105,11 @@ class GraphedMiStep:
                       self.sid.data_ptr(), self.sid.data_ptr(), self.b, self.b, 0, self.dx, self.dy, self.est, self.prec, 1,
                       self.loss_buf.data_ptr(), self.stats.data_ptr(), self.record.data_ptr(), None, self.ws.data_ptr(),
                       self.ws.numel())
+        elif self.kind == "separable":
+            _hip.call("mi_separable_fwd", self.device, self.x.data_ptr(), self.y.data_ptr(), p[0].data_ptr(), p[1].data_ptr(),
+                      self.sid.data_ptr(), self.sid.data_ptr(), self.b, self.b, 0, self.dx, self.dy, self.k, self.est,
+                      self.prec, 1, self.loss_buf.data_ptr(), self.stats.data_ptr(), self.record.data_ptr(),
+                      self.ws.data_ptr(), self.ws.numel())
         else:
             _hip.call("mi_concat_mlp_fwd", self.device, self.x.data_ptr(), self.y.data_ptr(), p[0].data_ptr(),
                       p[1].data_ptr(), p[2].data_ptr(), p[3].data_ptr(), p[4].data_ptr(), p[5].data_ptr(),
@@ -114,6 +124,11 @@ class GraphedMiStep:
                       self.sid.data_ptr(), self.sid.data_ptr(), self.b, self.b, 0, self.dx, self.dy, self.prec,
                       self.stats.data_ptr(), self.grad_out.data_ptr(), self.grad_x.data_ptr(), self.grad_y.data_ptr(),
                       g[0].data_ptr() if g else None, self.ws.data_ptr(), self.ws.numel(), 1)
+        elif self.kind == "separable":
+            _hip.call("mi_separable_bwd", self.device, self.x.data_ptr(), self.y.data_ptr(), p[0].data_ptr(), p[1].data_ptr(),
+                      self.sid.data_ptr(), self.sid.data_ptr(), self.b, self.b, 0, self.dx, self.dy, self.k, self.prec,
+                      self.stats.data_ptr(), self.grad_out.data_ptr(), self.grad_x.data_ptr(), self.grad_y.data_ptr(),
+                      g[0].data_ptr(), g[1].data_ptr(), self.ws.data_ptr(), self.ws.numel(), 1)
         else:
             _hip.call("mi_concat_mlp_bwd", self.device, self.x.data_ptr(), self.y.data_ptr(), p[0].data_ptr(),
                       p[1].data_ptr(), p[2].data_ptr(), p[3].data_ptr(), p[4].data_ptr(), p[5].data_ptr(),

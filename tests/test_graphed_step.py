@@ -19,13 +19,16 @@ def dev():
 
 
 def _critic(kind, d, dev):
-    from mutual_info_img_txt.model import BilinearCritic, make_mlp
+    from mutual_info_img_txt.model import BilinearCritic, SeparableCritic, make_mlp
     torch.manual_seed(5)
+    if kind == "separable":
+        return SeparableCritic(d, d, d).to(dev)
     return (BilinearCritic(d, d) if kind == "bilinear" else make_mlp(2 * d, [128, 256])).to(dev)
 
 
 @pytest.mark.parametrize("kind,precision,b,d,est", [("bilinear", "bf16", 512, 256, "infonce"), ("bilinear", "f32", 96, 64, "dv"),
-                                                    ("concat_mlp", "f32", 96, 32, "dv"), ("concat_mlp", "bf16", 128, 64, "infonce")])
+                                                    ("concat_mlp", "f32", 96, 32, "dv"), ("concat_mlp", "bf16", 128, 64, "infonce"),
+                                                    ("separable", "bf16", 256, 256, "infonce"), ("separable", "f32", 96, 64, "dv")])
 def test_graphed_step_bit_identical_to_eager(dev, kind, precision, b, d, est):
     from mutual_info_img_txt import mi_critics
     from mutual_info_img_txt.graphed import GraphedMiStep
