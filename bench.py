@@ -47,8 +47,8 @@ import torch.distributed as dist  # noqa: E402
 PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3,  # dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md
                "f32_exact": 157.3,       # v_mfma_f32_32x32x2_f32 products ("f32" on the bilinear critic runs bf16x3)
                "bf16x3": 2500.0 / 3,     # three bf16 MFMAs per algorithmic product
-               "fp8": 5000.0}            # the dense fp8 peak (MX-scaled fp8 MFMA); this build's forward products use the
-                                         # non-scaled v_mfma_f32_32x32x16_fp8_fp8 (bf16 rate) and a bf16 backward
+               "fp8": 5000.0}            # the dense fp8 peak: the forward products run on v_mfma_scale_f32_32x32x64_f8f6f4
+                                         # with unit block scales; the backward's contractions are bf16
 PEAK_HBM_GBS = 8000.0
 
 
@@ -565,7 +565,7 @@ def main():
             fl4 = algorithmic_flops("bilinear", b8, d8, d8)
             out["fp8_mode"] = {
                 "workload": f"BASELINE configs[4] on one GPU: fp8 (e4m3, per-tensor scale absmax / 448) bilinear critic "
-                            f"fwd+bwd, B={b8}, d={d8}; forward products on v_mfma_f32_32x32x16_fp8_fp8, backward on bf16 MFMA",
+                            f"fwd+bwd, B={b8}, d={d8}; forward products on v_mfma_scale_f32_32x32x64_f8f6f4 (unit block scales), backward on bf16 MFMA",
                 "value": round(b8 / (ms4 * 1e-3), 1), "unit": "pairs/s", "ms_per_step": round(ms4, 4), "steps": n8,
                 "loss": st4.loss(), "step_algorithmic_tflops": round(fl4 / (ms4 * 1e-3) / 1e12, 2),
                 "step_frac_of_peak": round(fl4 / (ms4 * 1e-3) / 1e12 / PEAK_TFLOPS["fp8"], 5),

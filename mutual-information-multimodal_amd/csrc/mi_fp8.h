@@ -3,7 +3,7 @@
 // quantised inputs -- oracle/mi_oracle.py bilinear_step_fp8).  The reference has no such path (it is fp32 throughout).
 //
 //   x_q = e4m3(x / s_x), s_x = absmax(x) / 448            (same for y, W; scales and divisions in fp32, on the device)
-//   T   = s_x s_w (x_q W_q)        v_mfma_f32_32x32x16_fp8_fp8: exact products, fp32 accumulation
+//   T   = s_x s_w (x_q W_q)        v_mfma_scale_f32_32x32x64_f8f6f4, unit block scales: exact products, fp32 accumulation
 //   t_q = e4m3(T / s_t)            its own per-tensor scale (the amax rides on the T product's epilogue)
 //   S   = s_t s_y (t_q y_q^T)      fp8 MFMA again; masked log-sum-exp epilogue as in the bf16 path
 // The backward treats the quantisers as straight-through and runs on the bf16 kernels with the quantised VALUES as
@@ -132,13 +132,18 @@ static __global__ __launch_bounds__(256) void fp8_quantize_kernel(QuantJobs jobs
 
 // ------------------------------------------------------------------------------------------------ fp8 GEMM
 // C[m][n] = sum_k A[m][k] B[n][k], both operands e4m3, K-contiguous.  128 x 128 tile, 4 waves of 64 x 64, k-step 128
-// (128-byte rows), register-staged double buffer; LDS rows are 136 bytes apart (34 dwords: the 32 rows of an 8-byte
-// fragment read fall on 32 distinct even banks).  The fragment geometry is that of the bf16 32x32x16 instruction (lane:
-// row lane & 31, the 8 K elements 8 (lane >> 5) .. + 7) with one byte per element; the accumulator layout is the same,
-// so every epilogue of mi_gemm_bf16.h applies unchanged.
+// (128-byte rows), register-staged double buffer; LDS rows are 144 bytes apart.
 constexpr int kF8KT = 128;  // k per tile (bytes per row)
-constexpr int kF8LD = 136;  // LDS row pitch in bytes
-constexpr size_t kF8Smem = 2 * 2 * kTile * kF8LD;  // 69,632 bytes (>= 4 epilogue staging areas)
+constexpr int kF8LD = 144;  // LDS row pitch in bytes: 16-byte aligned rows, 36 dwords = 4 x odd -> the 16-lane groups of a
+                            // ds_read_b128 over rows r32 fall on 16 distinct 4-bank spans
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+// The products run on v_mfma_scale_f32_32x32x64_f8f6f4 with unit block scales (E8M0 127 = 2^0): K = 64 per instruction
+// at twice the rate of v_mfma_f32_32x32x16_fp8_fp8 (the dense fp8 peak of the chip, 5 PFLOP/s).  A lane holds 32
+// consecutive K bytes of its row: bytes [32 half, 32 half + 32) of the 64-deep step, for the A and the B operand alike --
+// whatever order the instruction gives the bytes inside a lane, the two operands agree on it, which is all a dot product
+// over K needs; the accumulator layout is the 32 x 32 one of the bf16 instruction, so every epilogue still applies.
+constexpr int kF8UnitScale = 0x7F7F7F7F;
+constexpr size_t kF8Smem = 2 * 2 * kTile * kF8LD;  // 73,728 bytes (>= 4 epilogue staging areas)
 
 struct GemmF8Args {
   const fp8_t* a;
@@ -152,8 +157,8 @@ template <class Epi>
 __global__ __launch_bounds__(256, 2) void gemm_fp8_kernel(GemmF8Args P, Epi epi) {
   kernarg_prefetch<(int)(sizeof(GemmF8Args) + sizeof(Epi))>();
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  char* As = smem_raw;                       // [2][128][136]
-  char* Bs = smem_raw + 2 * kTile * kF8LD;   // [2][128][136]
+  char* As = smem_raw;                       // [2][128][144]
+  char* Bs = smem_raw + 2 * kTile * kF8LD;   // [2][128][144]
   int bx_, by_;
   xcd_tile(bx_, by_);
   const int64_t m0 = (int64_t)by_ * kTile, n0 = (int64_t)bx_ * kTile;
@@ -186,13 +191,9 @@ __global__ __launch_bounds__(256, 2) void gemm_fp8_kernel(GemmF8Args P, Epi epi)
   };
   auto store_tile = [&](int buf) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {  // 136-byte rows are 8-byte aligned: two 8-byte stores per chunk
-      char* pa = As + (buf * kTile + srow + 32 * q) * kF8LD + sch * 16;
-      char* pb = Bs + (buf * kTile + srow + 32 * q) * kF8LD + sch * 16;
-      *reinterpret_cast<uint2*>(pa) = uint2{ra[q][0], ra[q][1]};
-      *reinterpret_cast<uint2*>(pa + 8) = uint2{ra[q][2], ra[q][3]};
-      *reinterpret_cast<uint2*>(pb) = uint2{rb[q][0], rb[q][1]};
-      *reinterpret_cast<uint2*>(pb + 8) = uint2{rb[q][2], rb[q][3]};
+    for (int q = 0; q < 4; ++q) {
+      *reinterpret_cast<u32x4*>(As + (buf * kTile + srow + 32 * q) * kF8LD + sch * 16) = ra[q];
+      *reinterpret_cast<u32x4*>(Bs + (buf * kTile + srow + 32 * q) * kF8LD + sch * 16) = rb[q];
     }
   };
 
@@ -207,19 +208,29 @@ __global__ __launch_bounds__(256, 2) void gemm_fp8_kernel(GemmF8Args P, Epi epi)
     const char* at = As + buf * kTile * kF8LD;
     const char* bt = Bs + buf * kTile * kF8LD;
 #pragma unroll
-    for (int kk = 0; kk < kF8KT / 16; ++kk) {
-      long af[2], bfr[2];
+    for (int kk = 0; kk < kF8KT / 64; ++kk) {
+      union Frag {
+        i32x8 v;
+        u32x4 h[2];
+      } af[2], bfr[2];
 #pragma unroll
-      for (int tm = 0; tm < 2; ++tm)
-        af[tm] = *reinterpret_cast<const long*>(at + (wm * 64 + tm * 32 + r32) * kF8LD + kk * 16 + 8 * half);
+      for (int tm = 0; tm < 2; ++tm) {
+        const char* src = at + (wm * 64 + tm * 32 + r32) * kF8LD + kk * 64 + 32 * half;
+        af[tm].h[0] = *reinterpret_cast<const u32x4*>(src);
+        af[tm].h[1] = *reinterpret_cast<const u32x4*>(src + 16);
+      }
 #pragma unroll
-      for (int tn = 0; tn < 2; ++tn)
-        bfr[tn] = *reinterpret_cast<const long*>(bt + (wn * 64 + tn * 32 + r32) * kF8LD + kk * 16 + 8 * half);
+      for (int tn = 0; tn < 2; ++tn) {
+        const char* src = bt + (wn * 64 + tn * 32 + r32) * kF8LD + kk * 64 + 32 * half;
+        bfr[tn].h[0] = *reinterpret_cast<const u32x4*>(src);
+        bfr[tn].h[1] = *reinterpret_cast<const u32x4*>(src + 16);
+      }
 #pragma unroll
       for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
         for (int tn = 0; tn < 2; ++tn)
-          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(af[tm], bfr[tn], acc[tm][tn], 0, 0, 0);
+          acc[tm][tn] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(af[tm].v, bfr[tn].v, acc[tm][tn], 0, 0, 0,
+                                                                        kF8UnitScale, 0, kF8UnitScale);
     }
     if (more) store_tile(buf ^ 1);
     __syncthreads();
