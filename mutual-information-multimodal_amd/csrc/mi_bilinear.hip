@@ -435,10 +435,10 @@ static int bilinear_fwd_fp8(const float* x, const float* y, const float* w, cons
   int rc = staged ? MI_OK : fp8_prep_and_t(x, y, w, br, b, dx, dy, p, st);  // staged: mi_bilinear_fp8_stage made them
   if (rc) return rc;
   EpiScaled<EpiScoreLse2> e{EpiScoreLse2{sid_rows, sid_cols, row_offset, scores_out, p.partials},
-                            {&p.f8sc->scale[3], nullptr}, {&p.f8sc->scale[1], nullptr}};
+                            {&p.f8sc->scale[3], nullptr}, {&p.f8sc->scale[1], nullptr}, p.partials};
   rc = launch_gemm_fp8(GemmF8Args{p.qt8, dy, p.qy8, dy, br, b, dy}, e, st, "fp8 score+LSE");
   if (rc) return rc;
-  return launch_finalize(p.partials, p.n_partials, b, estimator, loss_out, stats, partials_out, st);
+  return launch_finalize(p.partials, gemm_fp8_n_partials(br, b, dy), b, estimator, loss_out, stats, partials_out, st);
 }
 
 static int bilinear_bwd_fp8(const int64_t* sid_rows, const int64_t* sid_cols, int64_t br, int64_t b, int64_t row_offset,

@@ -238,11 +238,38 @@ __global__ __launch_bounds__(256, 2) void gemm_fp8_kernel(GemmF8Args P, Epi epi)
   epi(acc, m0 + wm * 64, n0 + wn * 64, P.m, P.n, 0, 0, smem_raw + wave * kEpiLdsPerWave);
 }
 
+// Large single problems (the B x B score products) take the 256 x 256 LDS-DMA kernel of mi_gemm_bf16.h in its fp8 form;
+// it writes one partial per 256 x 256 tile (gemm_fp8_n_partials).  MI_FP8_NO_BIG=1: A/B switch.
+static inline bool gemm_fp8_use_big(int64_t m, int64_t n, int64_t k) {
+  static const bool off = getenv("MI_FP8_NO_BIG") != nullptr;
+  return !off && k % 128 == 0 && k > 0 && ((m + 255) / 256) * ((n + 255) / 256) >= 192;
+}
+static inline int64_t gemm_fp8_n_partials(int64_t m, int64_t n, int64_t k) {
+  const int64_t t = gemm_fp8_use_big(m, n, k) ? 256 : kTile;
+  return ((m + t - 1) / t) * ((n + t - 1) / t);
+}
+
 template <class Epi>
 static inline int launch_gemm_fp8(const GemmF8Args& a, const Epi& epi, hipStream_t st, const char* what) {
   if (a.k % 16 != 0 || a.lda % 16 != 0 || a.ldb % 16 != 0 || (uintptr_t)a.a % 16 != 0 || (uintptr_t)a.b % 16 != 0) {
     set_error("%s: the fp8 GEMM needs K and the row pitches to be multiples of 16", what);
     return MI_ESHAPE;
+  }
+  if (gemm_fp8_use_big(a.m, a.n, a.k)) {
+    GemmBf16Args args{};  // units of two bytes: see gemm_bf16_big_kernel<Epi, true>
+    args.p[0] = GemmBf16Problem{reinterpret_cast<const bf16_t*>(a.a), a.lda / 2, reinterpret_cast<const bf16_t*>(a.b),
+                                a.ldb / 2, a.m, a.n, a.k / 2};
+    args.n_problems = 1;
+    args.k_chunk = a.k / 2;
+    MI_SET_DYN_SMEM((gemm_bf16_big_kernel<Epi, true>), kG2SmemBig, "hipFuncSetAttribute(gemm_bf16_big_kernel fp8)");
+    dim3 grid((unsigned)((a.n + 255) / 256), (unsigned)((a.m + 255) / 256), 1);
+    xcd_pick_blocks(grid.y, grid.x, 256, a.k / 2, 1, args.xcd_gy, args.xcd_gx);
+    {
+      ProfScope prof_(what, st);
+      hipLaunchKernelGGL((gemm_bf16_big_kernel<Epi, true>), grid, dim3(512), kG2SmemBig, st, args, epi);
+    }
+    MI_LAUNCH_CHECK(what);
+    return MI_OK;
   }
   MI_SET_DYN_SMEM((gemm_fp8_kernel<Epi>), kF8Smem, "hipFuncSetAttribute(gemm_fp8_kernel)");
   dim3 grid((unsigned)((a.n + kTile - 1) / kTile), (unsigned)((a.m + kTile - 1) / kTile), 1);
@@ -261,6 +288,18 @@ struct EpiScaled {
   Inner inner;
   const float* sa[2];
   const float* sb[2];
+  Partial* partials = nullptr;  // = inner.partials for a reducing epilogue (the 256 x 256 kernel writes them itself)
+  __device__ __forceinline__ Partial lane_partial(f32x16 (&acc)[2][2], int64_t mb, int64_t nb, int64_t M, int64_t N) const {
+    const float f = (sa[0] ? sa[0][0] : 1.0f) * (sb[0] ? sb[0][0] : 1.0f);
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+      for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[tm][tn][r] *= f;
+    if constexpr (Inner::kReducesPartial) return inner.lane_partial(acc, mb, nb, M, N);
+    else return Partial{};
+  }
   __device__ __forceinline__ void operator()(f32x16 (&acc)[2][2], int64_t mb, int64_t nb, int64_t M, int64_t N, int prob,
                                              int zsplit, char* lds) const {
     const float f = (sa[prob] ? sa[prob][0] : 1.0f) * (sb[prob] ? sb[prob][0] : 1.0f);

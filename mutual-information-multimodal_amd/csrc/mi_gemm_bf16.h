@@ -1120,12 +1120,18 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_pipe_kernel(GemmBf16Args arg
 // and reads 6 fragments per 8 MFMAs instead of 4 per 4.  512 threads = 8 waves (2 x 4), each 128 x 64 = 4 x 2 MFMA
 // tiles (128 accumulator registers); same LDS-DMA + XOR swizzle as above; 2 x 64 KB of LDS, one workgroup per CU, so a
 // 4096 x 4096 problem is exactly one workgroup per CU.  Single problem, no split-K.
-template <class Epi>
+// FP8 = true (mi_fp8.h): the same kernel on e4m3 operands -- a 128-byte tile row is then 128 K elements instead of 64;
+// the problem's pointers, pitches and K are passed in units of two bytes, so staging and swizzle are byte-identical and
+// only the fragment reads (32 bytes per lane and 64-deep step: chunks 4 kk + 2 half, + 1) and the MFMA
+// (v_mfma_scale_f32_32x32x64_f8f6f4, unit block scales) differ.
+typedef int i32x8_t __attribute__((ext_vector_type(8)));
+template <class Epi, bool FP8 = false>
 __global__ __launch_bounds__(512, 1) void gemm_bf16_big_kernel(GemmBf16Args args, Epi epi) {
   kernarg_prefetch<(int)(sizeof(GemmBf16Args) + sizeof(Epi))>();
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   // [buf][A | B][256 rows][128 bytes]
-  const GemmBf16Problem& P = args.p[0];
+  const int prob = (int)blockIdx.z;  // two independent problems in one grid (dT | dY of the G-materialising paths)
+  const GemmBf16Problem& P = args.p[prob];
   int bx_, by_;
   if (args.xcd_gy) xcd_block_tile(args.xcd_gy, args.xcd_gx, bx_, by_);
   else xcd_tile(bx_, by_);
@@ -1207,18 +1213,50 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_big_kernel(GemmBf16Args args
       for (int tn = 0; tn < 2; ++tn)
         bfr[slot][tn] = *reinterpret_cast<const bf16x8*>(bt + boff[tn] + 16 * ((2 * kk + half) ^ bswz[tn]));
     };
-    read_frags(0, 0);
+    if constexpr (FP8) {
+      union Frag8 {
+        i32x8_t v;
+        u32x4 h[2];
+      } a8[2][4], b8[2][2];
+      auto read8 = [&](int kk, int slot) {
 #pragma unroll
-    for (int kk = 0; kk < kG2KT / 16; ++kk) {
-      if (kk + 1 < kG2KT / 16) read_frags(kk + 1, (kk + 1) & 1);  // ahead of this step's MFMAs
-      __builtin_amdgcn_sched_barrier(0);
+        for (int tm = 0; tm < 4; ++tm) {
+          a8[slot][tm].h[0] = *reinterpret_cast<const u32x4*>(at + aoff[tm] + 16 * ((4 * kk + 2 * half) ^ aswz[tm]));
+          a8[slot][tm].h[1] = *reinterpret_cast<const u32x4*>(at + aoff[tm] + 16 * ((4 * kk + 2 * half + 1) ^ aswz[tm]));
+        }
 #pragma unroll
-      for (int tm = 0; tm < 4; ++tm)
+        for (int tn = 0; tn < 2; ++tn) {
+          b8[slot][tn].h[0] = *reinterpret_cast<const u32x4*>(bt + boff[tn] + 16 * ((4 * kk + 2 * half) ^ bswz[tn]));
+          b8[slot][tn].h[1] = *reinterpret_cast<const u32x4*>(bt + boff[tn] + 16 * ((4 * kk + 2 * half + 1) ^ bswz[tn]));
+        }
+      };
+      read8(0, 0);
 #pragma unroll
-        for (int tn = 0; tn < 2; ++tn)
-          acc[tm >> 1][tm & 1][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[kk & 1][tm], bfr[kk & 1][tn],
-                                                                             acc[tm >> 1][tm & 1][tn], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
+      for (int kk = 0; kk < 2; ++kk) {
+        if (kk == 0) read8(1, 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+          for (int tn = 0; tn < 2; ++tn)
+            acc[tm >> 1][tm & 1][tn] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(
+                a8[kk][tm].v, b8[kk][tn].v, acc[tm >> 1][tm & 1][tn], 0, 0, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else {
+      read_frags(0, 0);
+#pragma unroll
+      for (int kk = 0; kk < kG2KT / 16; ++kk) {
+        if (kk + 1 < kG2KT / 16) read_frags(kk + 1, (kk + 1) & 1);  // ahead of this step's MFMAs
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+          for (int tn = 0; tn < 2; ++tn)
+            acc[tm >> 1][tm & 1][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[kk & 1][tm], bfr[kk & 1][tn],
+                                                                               acc[tm >> 1][tm & 1][tn], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
     __syncthreads();
   }
@@ -1237,9 +1275,9 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_big_kernel(GemmBf16Args args
     if (threadIdx.x == 0) epi.partials[(int64_t)blockIdx.y * gridDim.x + blockIdx.x] = p;
   } else {
     char* lds = smem_raw + wave * kEpiLdsPerWave;
-    epi(acc[0], mb, nb, P.m, P.n, 0, 0, lds);
+    epi(acc[0], mb, nb, P.m, P.n, prob, 0, lds);
     MI_STAMP(6);
-    epi(acc[1], mb + 64, nb, P.m, P.n, 0, 0, lds);
+    epi(acc[1], mb + 64, nb, P.m, P.n, prob, 0, lds);
     MI_STAMP(7);
   }
   MI_STAMP(5);
@@ -1289,9 +1327,16 @@ static inline int launch_gemm_bf16(const GemmBf16Args& args_in, int n_splits, co
                     "hipFuncSetAttribute(gemm_bf16_pipe_kernel 128)");
   bool dma_ok = args.k_chunk % kG2KT == 0 || n_splits == 1;
   for (int q = 0; q < args.n_problems; ++q) dma_ok = dma_ok && args.p[q].k % kG2KT == 0 && args.p[q].k > 0;
-  if (dma_ok && args.n_problems == 1 && n_splits == 1 && gemm_bf16_use_big(mm, nn, args.p[0].k)) {
+  // two long-K problems that fill the chip with 256 x 256 tiles together (dT | dY at B = 8192: 2 x 128 tiles): the
+  // same kernel, blockIdx.z = problem.  MI_GEMM_NO_BIG2=1: A/B switch.
+  static const bool no_big2 = getenv("MI_GEMM_NO_BIG2") != nullptr;
+  bool big2 = false;
+  if constexpr (!Epi::kReducesPartial)
+    big2 = !no_big2 && dma_ok && args.n_problems == 2 && n_splits == 1 && args.p[0].k >= 2048 && args.p[1].k >= 2048 &&
+           !gemm_old_kernels() && 2 * ((mm + 255) / 256) * ((nn + 255) / 256) >= 192;
+  if (big2 || (dma_ok && args.n_problems == 1 && n_splits == 1 && gemm_bf16_use_big(mm, nn, args.p[0].k))) {
     MI_SET_DYN_SMEM((gemm_bf16_big_kernel<Epi>), kG2SmemBig, "hipFuncSetAttribute(gemm_bf16_big_kernel)");
-    dim3 grid((unsigned)((nn + 255) / 256), (unsigned)((mm + 255) / 256), 1);
+    dim3 grid((unsigned)((nn + 255) / 256), (unsigned)((mm + 255) / 256), (unsigned)args.n_problems);
     xcd_pick_blocks(grid.y, grid.x, 256, args.p[0].k, 1, args.xcd_gy, args.xcd_gx);
     MI_STAMP_SELECT(what, st);
     {
