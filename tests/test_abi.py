@@ -49,6 +49,30 @@ def test_argument_validation_without_gpu(lib):
     assert lib.mi_merge_partials(None, 1, 1, 0, None, None, None) == -1
 
 
+def test_round3_entry_points_validate_without_gpu(lib):
+    """mi_bilinear_step / prep_local / fp8_stage / bwd_records reject bad arguments before anything touches the device,
+    and mi_bilinear_raw_records is a pure host query."""
+    import ctypes
+    assert lib.mi_bilinear_step(None, None, None, None, 64, 128, 128, 1, 1, None, None, None, None, None, None, None, None, 0,
+                                None) == -1
+    assert b"null" in lib.mi_last_error()
+    assert lib.mi_bilinear_prep_local(None, None, 64, 64, 128, 128, 1, None, 0, None) == -1
+    assert lib.mi_bilinear_fp8_stage(None, None, None, 64, 64, 128, 128, 0, None, None, 0, None) == -1
+    assert lib.mi_bilinear_bwd_records(None, None, None, None, None, 64, 64, 0, 128, 128, 1, 1, None, 0, 0, None, None, None,
+                                       None, None, None, None, 0, None) == -1
+    off = ctypes.c_size_t(0)
+    # 512-row block of a 4096 batch at d = 512, bf16: 4 row blocks of 128 x 32 column splits (the plan fills the 256 CUs)
+    # x 4 waves = 512 records of 16 bytes
+    n = lib.mi_bilinear_raw_records(512, 4096, 512, 512, 1, ctypes.byref(off))
+    assert n == 512 and off.value % 256 == 0
+    assert off.value + 16 * n <= lib.mi_bilinear_workspace_bytes(512, 4096, 512, 512, 1)
+    assert lib.mi_bilinear_raw_records(4096, 4096, 512, 512, 1, None) == 512  # 32 row blocks x 4 splits x 4 waves
+    # shapes / precisions outside the fused kernels have no raw records
+    assert lib.mi_bilinear_raw_records(512, 4096, 768, 768, 1, None) == 0      # width 768
+    assert lib.mi_bilinear_raw_records(500, 4096, 512, 512, 1, None) == 0      # ragged row block
+    assert lib.mi_bilinear_raw_records(512, 4096, 512, 512, 0, None) == 0      # f32
+
+
 def test_no_cpu_fallback():
     from mutual_info_img_txt import mi_critics
     from mutual_info_img_txt._hip import MiCriticError
