@@ -220,7 +220,7 @@ def test_split_forward_equals_the_one_call(dev, b, d, G, prec):
     assert odd.prep_local(xs[:, :d - 4].contiguous(), [w[:d - 4].contiguous()], b, pc) is False and odd._local_ws is None
 
 
-@pytest.mark.parametrize("b,d,G", [(1024, 512, 2), (512, 256, 4)])
+@pytest.mark.parametrize("b,d,G", [(1024, 512, 2), (512, 256, 4), (4096, 512, 8)])  # the last: BASELINE configs[3]
 def test_raw_record_row_blocks_equal_record_path(dev, b, d, G):
     """Sharded runs without the finalize / merge launches: mi_bilinear_fwd(need_grad | 8) per row block, the blocks' raw
     per-wave records concatenated in block order (= the all-gather), mi_bilinear_bwd_records per block.  Every block gets
