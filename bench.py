@@ -15,8 +15,12 @@ A step = pair enumeration + scorer + bound + ALL gradients (dX, dY, d theta) thr
 issued as direct calls or replayed from hipGraphs (`--graph auto`, the default, times both during warm-up and keeps the
 faster; `--graph on|off` forces one).  Encoders, optimisers and data loading are not in the metric.
 
+Before the W warm-up steps the GPU is brought to the clocks of a sustained run by about 300 ms of untimed steps
+(`--clock-warmup-ms`, 0 = off; reported in `timing.clock_warmup`): 20 timed steps that start cold take ~5 % longer each
+than the same steps inside a long run.
+
 One JSON line on stdout (rank 0): the driver's contract (`value` from exactly K steps between barriers / synchronize),
-plus `timing` (median / p10 / p90 of >= 50 individually hipEvent-timed steps, graph and eager), `roofline` (dominant
+plus `separable_mode` (BASELINE configs[1]), `timing` (median / p10 / p90 of >= 50 individually hipEvent-timed steps, graph and eager), `roofline` (dominant
 kernel, HIP-event timed through the library's profiling hook; measured HBM bytes and matrix-pipe busy fraction from the
 newest committed PMC pass of the SAME kernel sources), `parity_mode` (the same step in the modes held to fp32 tolerances:
 "f32_exact" and "bf16x3"), `fp8_mode` (BASELINE configs[4] on one GPU: B = 8192, d = 1024), `secondary` (the reference's own
