@@ -132,7 +132,7 @@ int mi_create_pairs_bwd(const float* grad_out, const int32_t* rowpos, int64_t b,
  * sid_cols [b]; row_offset = global index of local row 0 (diagonal of the global B x B matrix).  Single GPU:
  * b_rows = b, row_offset = 0.  scores_out (optional) [b_rows, b].  w == NULL selects the separable form
  * S = X Y^T on already-projected embeddings (d_img == d_txt; grad_w unused).
- * need_grad != 0: the forward's fused B x B launch also accumulates the two gradient contractions (the loss has one
+ * need_grad bit 0: the forward's fused B x B launch also accumulates the two gradient contractions (the loss has one
  * global log-sum-exp, so they only need a scale once it is known); the matching backward then never recomputes scores. */
 size_t mi_bilinear_workspace_bytes(int64_t b_rows, int64_t b, int64_t d_img, int64_t d_txt, int precision);
 int mi_bilinear_fwd(const float* x, const float* y, const float* w, const int64_t* sid_rows,

@@ -253,7 +253,9 @@ static int bilinear_fwd_fast(const float* x, const float* y, const float* w, con
   int rc = fast_prep_and_t(x, y, w, sid_rows, sid_cols, br, b, row_offset, dx, dy, p, st, (need_grad & 4) && p.fl.ok ? 2 : 0);
   if (rc) return rc;
   if (p.fl.ok) {
-    rc = flash_stage(sid_rows, sid_cols, br, b, row_offset, dy, need_grad != 0, p, st);
+    // bit 0: gradients wanted (the fused launch then accumulates both contractions); bits 1-3 are flags (fp8 staged,
+    // local part prepared, raw records)
+    rc = flash_stage(sid_rows, sid_cols, br, b, row_offset, dy, (need_grad & 1) != 0, p, st);
     if (rc) return rc;
     if (scores_out) {  // per-pair scores are a diagnostic output: the stand-alone score GEMM writes them
       rc = launch_gemm_bf16(one_problem(p.tb, dy, p.yb, dy, br, b, dy), 1,

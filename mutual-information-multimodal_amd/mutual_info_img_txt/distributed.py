@@ -35,6 +35,7 @@ class HipBilinearOps:
     def __init__(self):
         self._fp8_ws = None    # workspace of a staged fp8 preparation, handed on to forward()
         self._local_ws = None  # workspace in which prep_local() prepared the rank's own part, handed on to forward()
+        self._local_key = None
 
     def prep_local(self, x, params, b, precision) -> bool:
         """The part of the forward that needs neither the gathered text embeddings nor the gathered ids -- bf16 copies of
@@ -54,7 +55,15 @@ class HipBilinearOps:
             return False
         _hip.check(rc, "mi_bilinear_prep_local")
         self._local_ws = ws
+        self._local_key = (x.data_ptr(), w.data_ptr(), br, b, dx, dy, precision)
         return True
+
+    def _take_local_ws(self, x, w, br, b, dx, dy, precision):
+        """The workspace prep_local() filled -- only for the call it was made for (same tensors, shapes, precision)."""
+        ws, self._local_ws = self._local_ws, None
+        if ws is not None and self._local_key != (x.data_ptr(), w.data_ptr(), br, b, dx, dy, precision):
+            return None  # a prep_local() whose forward never came: not this call's
+        return ws
 
     def fp8_stage(self, stage, x, y_all, params, amax):
         """One stage of the fp8 mode's preparation (mi_bilinear_fp8_stage): ``amax`` (4 floats on the device: x, y, W, T)
@@ -79,11 +88,12 @@ class HipBilinearOps:
         if staged:
             ws, self._fp8_ws = self._fp8_ws, None
             need_grad = int(bool(need_grad)) | 2  # bit 1: the fp8 operands are staged in this workspace
-        elif self._local_ws is not None:
-            ws, self._local_ws = self._local_ws, None
-            need_grad = int(bool(need_grad)) | 4  # bit 2: prep_local() already ran in this workspace
         else:
-            ws = _hip.workspace(lib.mi_bilinear_workspace_bytes(br, b, dx, dy, precision), dev)
+            ws = self._take_local_ws(x, w, br, b, dx, dy, precision)
+            if ws is not None:
+                need_grad = int(bool(need_grad)) | 4  # bit 2: prep_local() already ran in this workspace
+            else:
+                ws = _hip.workspace(lib.mi_bilinear_workspace_bytes(br, b, dx, dy, precision), dev)
         stats = _hip.new_stats(dev)
         loss = torch.empty(1, dtype=torch.float32, device=dev)
         record = torch.empty(_hip.RECORD_FLOATS, dtype=torch.float32, device=dev)
@@ -108,8 +118,8 @@ class HipBilinearOps:
             return None
         dev = x.device
         flags = 1 | 8
-        if self._local_ws is not None:
-            ws, self._local_ws = self._local_ws, None
+        ws = self._take_local_ws(x, w, br, b, dx, dy, precision)
+        if ws is not None:
             flags |= 4
         else:
             ws = _hip.workspace(lib.mi_bilinear_workspace_bytes(br, b, dx, dy, precision), dev)
