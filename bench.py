@@ -651,12 +651,12 @@ def main():
         out["cpu_baseline"] = cpu_baseline(args.critic, args)
         if "secondary" in out and "error" not in out["secondary"]:
             out["secondary"]["cpu_baseline"] = cpu_baseline("concat_mlp" if args.critic == "bilinear" else "bilinear", args)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
-    if rank == 0:
+    if rank == 0:  # the line first: a tear-down problem must not cost the measurement
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())
+    if dist.is_initialized():  # several ranks, or the one-rank rehearsal of the RCCL path (MI_BENCH_FORCE_DIST)
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":
