@@ -54,6 +54,10 @@ PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3,  # dense MFMA peaks, /opt/skills/gu
                "fp8": 5000.0}            # the dense fp8 peak: the forward products run on v_mfma_scale_f32_32x32x64_f8f6f4
                                          # with unit block scales; the backward's contractions are bf16
 PEAK_HBM_GBS = 8000.0
+# the secondary leg (the reference's concat-MLP critic): fast 16-bit modes, the first one is the `secondary` number; and
+# the modes that hold the fp32 tolerances
+SECONDARY_FAST = {"concat_mlp": ["bf16"]}
+SECONDARY_PARITY = ["f32"]
 
 
 def parse_args():
@@ -421,6 +425,8 @@ def roofline_of(kernels, br, b, d, precision):
     ok = c is not None and not c.get("stale")
     return {"kernel": name, "bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
             "frac": round(achieved / peak, 4), "traffic": c["bytes"] if ok else None,
+            # achieved HBM-side rate of the same launch: counter bytes (committed PMC pass) / this run's event-timed duration
+            "hbm_gbs": round(c["bytes"] / (k["ms_avg"] * 1e-3) / 1e9, 1) if ok else None, "hbm_peak_gbs": PEAK_HBM_GBS,
             "mfma_busy_frac": c.get("mfma_busy_frac") if ok else None, "counters": c,
             "avg_us": round(k["ms_avg"] * 1e3, 2), "flops_per_launch": fl}
 
@@ -450,7 +456,7 @@ def fp8_roofline(kernels, b, d):
             "flops_per_launch": fl, "operands": "fp8 e4m3" if fp8_products else "bf16"}
 
 
-def cpu_baseline(kind, args):
+def cpu_baseline(kind, args, dim=None):
     """The oracle (a CPU port of the reference algorithm, pinned to the reference by tests/golden) timed on this box's
     host cores on a bounded sample of the same workload."""
     from oracle import mi_oracle as orc
@@ -459,9 +465,9 @@ def cpu_baseline(kind, args):
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
         avail = os.cpu_count() or 1
-    threads = max(1, min(avail, int(os.environ.get("MI_BENCH_CPU_THREADS", "16"))))
+    threads = max(1, min(avail, int(os.environ.get("MI_BENCH_CPU_THREADS", str(avail)))))
     torch.set_num_threads(threads)
-    d = args.dim
+    d = dim or args.dim
     if kind == "bilinear":
         b = args.batch
         gen = torch.Generator().manual_seed(3)
@@ -525,18 +531,21 @@ def main():
     want_graph = args.graph in ("on", "auto", "full")
     b, d, br = args.batch, args.dim, args.batch // world
 
-    def run(kind, steps, warmup, precision=None, timed_iters=0, batch=None, dim=None, clock_ms=None):
+    def run(kind, steps, warmup, precision=None, timed_iters=0, batch=None, dim=None, clock_ms=None, cold_first=False):
         st = Stepper(kind, args, rank, world, device, group, precision=precision, graph=want_graph, batch=batch, dim=dim)
         if args.graph == "auto":
             st.choose_launch_mode(world)
+        # the contract's W + K steps from a young process first (no clock warm-up): `cold_ms_per_step`
+        st.cold_elapsed = timed_run(st, steps, warmup, world) if cold_first else None
         st.clock_warmup_steps = clock_warmup(st, (args.clock_warmup_ms if clock_ms is None else clock_ms) * 1e-3, world)
         elapsed = timed_run(st, steps, warmup, world)
         timing = timing_summary(st, timed_iters) if timed_iters else None
         kernels = profile_kernels(st, args.profile_steps)
         return st, elapsed, kernels, timing
 
-    st, elapsed, kernels, timing = run(args.critic, args.steps, args.warmup, timed_iters=args.timed_iters)
+    st, elapsed, kernels, timing = run(args.critic, args.steps, args.warmup, timed_iters=args.timed_iters, cold_first=True)
     ms = elapsed / args.steps * 1e3
+    cold_ms = st.cold_elapsed / args.steps * 1e3
     flops = algorithmic_flops(args.critic, b, d, d)
     graph_mode = "none (direct C-ABI calls)" if st.use_eager else \
         ("one graph: kernels + the five RCCL collectives" if st.dist_mode and args.graph == "full" else
@@ -549,6 +558,8 @@ def main():
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": round(ms, 5),
+        "cold_ms_per_step": round(cold_ms, 5),
+        "warmup_effective_steps": args.warmup + st.clock_warmup_steps,
         "higher_is_better": True,
         "scaling": "strong",
         "vs_baseline": None,
@@ -561,7 +572,10 @@ def main():
                    "hip_graph": not st.use_eager, "graph_mode": graph_mode},
         "loss": st.loss(),
         "timing": dict(timing or {}, clock_warmup={"budget_ms": args.clock_warmup_ms, "untimed_steps": st.clock_warmup_steps,
-                                                   "note": "untimed steps before the W warm-up steps: sustained-run clocks"}),
+                                                   "note": "`ms_per_step`: untimed steps for budget_ms before the W warm-up "
+                                                           "steps (sustained-run clocks; the same budget for every leg of "
+                                                           "this line); `cold_ms_per_step`: the same W + K steps taken "
+                                                           "first, without them"}),
         "step_algorithmic_tflops": round(flops / (ms * 1e-3) / 1e12, 2),
         "step_frac_of_peak": round(flops / (ms * 1e-3) / 1e12 / (PEAK_TFLOPS[args.precision] * world), 5),
         "roofline": roofline_of(kernels, br, b, d, args.precision),
@@ -581,7 +595,7 @@ def main():
         for mode in ([exact, "bf16x3"] if args.critic == "bilinear" and world == 1 else [exact]):
             try:
                 n2 = max(3, args.steps // 10)
-                st2, el2, k2, _ = run(args.critic, n2, 2, precision=mode, clock_ms=min(args.clock_warmup_ms, 100.0))
+                st2, el2, k2, _ = run(args.critic, n2, 2, precision=mode)
                 ms2 = el2 / n2 * 1e3
                 out["parity_mode"][mode] = {
                     "ms_per_step": round(ms2, 4), "value": round(b / (ms2 * 1e-3), 1), "unit": "pairs/s",
@@ -596,7 +610,7 @@ def main():
         # BASELINE configs[4] on ONE GPU (the whole 8192 x 8192 score matrix, not a rank's 1024-row share)
         try:
             b8, d8, n8 = 8192, 1024, max(3, args.steps // 10)
-            st4, el4, k4, _ = run("bilinear", n8, 2, precision="fp8", batch=b8, dim=d8, clock_ms=min(args.clock_warmup_ms, 100.0))
+            st4, el4, k4, _ = run("bilinear", n8, 2, precision="fp8", batch=b8, dim=d8)
             ms4 = el4 / n8 * 1e3
             fl4 = algorithmic_flops("bilinear", b8, d8, d8)
             out["fp8_mode"] = {
@@ -615,7 +629,7 @@ def main():
         # BASELINE configs[1]: InfoNCE separable critic S = (X Wg)(Y Wh)^T, 256-d, batch 256, bf16, one GPU
         try:
             bs, ds, ns = 256, 256, max(20, args.steps)
-            st5, el5, k5, _ = run("separable", ns, 5, precision="bf16", batch=bs, dim=ds, clock_ms=min(args.clock_warmup_ms, 100.0))
+            st5, el5, k5, _ = run("separable", ns, 5, precision="bf16", batch=bs, dim=ds)
             ms5 = el5 / ns * 1e3
             fl5 = algorithmic_flops("separable", bs, ds, ds)
             out["separable_mode"] = {
@@ -631,26 +645,48 @@ def main():
         torch.cuda.empty_cache()
     if not args.no_secondary:
         other = "concat_mlp" if args.critic == "bilinear" else "bilinear"
-        try:
-            st3, el3, k3, _ = run(other, args.secondary_steps, 2, clock_ms=min(args.clock_warmup_ms, 100.0))
-            ms3 = el3 / args.secondary_steps * 1e3
-            fl3 = algorithmic_flops(other, b, d, d)
-            out["secondary"] = {
-                "workload": f"{other} critic fwd+bwd, B_global={b}, d={d}" + (" (the reference's mi_discriminator)" if other == "concat_mlp" else ""),
-                "value": round(b / (ms3 * 1e-3), 1), "unit": "pairs/s", "ms_per_step": round(ms3, 4),
-                "steps": args.secondary_steps, "hip_graph": not st3.use_eager, "loss": st3.loss(),
-                "step_algorithmic_tflops": round(fl3 / (ms3 * 1e-3) / 1e12, 2),
-                "step_frac_of_peak": round(fl3 / (ms3 * 1e-3) / 1e12 / (PEAK_TFLOPS[args.precision] * world), 5),
-                "roofline": roofline_of(k3, br, b, d, args.precision),
-                "kernels_us": {k: round(v["ms_avg"] * 1e3, 2) for k, v in sorted(k3.items(), key=lambda kv: -kv[1]["ms_total"])},
-            }
+        # the concat-MLP leg runs at the reference's own embedding width (768 per modality)
+        d2 = 768 if other == "concat_mlp" else d
+        fl3 = algorithmic_flops(other, b, d2, d2)
+
+        def leg(mode, n):
+            st3, el3, k3, _ = run(other, n, 2, precision=mode, dim=d2)
+            ms3 = el3 / n * 1e3
+            peak = PEAK_TFLOPS[mode] * world
+            res = {"precision": mode, "value": round(b / (ms3 * 1e-3), 1), "unit": "pairs/s", "ms_per_step": round(ms3, 4),
+                   "steps": n, "hip_graph": not st3.use_eager, "loss": st3.loss(),
+                   "step_algorithmic_tflops": round(fl3 / (ms3 * 1e-3) / 1e12, 2),
+                   "step_frac_of_peak": round(fl3 / (ms3 * 1e-3) / 1e12 / peak, 5), "peak": round(peak, 1),
+                   "roofline": roofline_of(k3, br, b, d2, mode),
+                   "kernels_us": {k: round(v["ms_avg"] * 1e3, 2) for k, v in sorted(k3.items(), key=lambda kv: -kv[1]["ms_total"])}}
             del st3
+            torch.cuda.empty_cache()
+            return res
+        try:
+            fast = SECONDARY_FAST.get(other, [args.precision])
+            out["secondary"] = dict(leg(fast[0], args.secondary_steps),
+                                    workload=f"{other} critic fwd+bwd, B_global={b}, d={d2}" +
+                                    (" (the reference's mi_discriminator, make_mlp(1536,[1024,512]))" if other == "concat_mlp" else ""))
+            for mode in fast[1:]:
+                try:
+                    out["secondary"].setdefault("other_fast_modes", {})[mode] = leg(mode, args.secondary_steps)
+                except Exception as e:
+                    out["secondary"].setdefault("other_fast_modes", {})[mode] = {"error": f"{type(e).__name__}: {e}"}
+            if not args.no_parity_mode and other == "concat_mlp":
+                # the reference's critic in the modes held to the fp32 tolerances
+                out["secondary"]["parity_mode"] = {}
+                for mode in SECONDARY_PARITY:
+                    try:
+                        out["secondary"]["parity_mode"][mode] = leg(mode, 3)
+                    except Exception as e:
+                        out["secondary"]["parity_mode"][mode] = {"error": f"{type(e).__name__}: {e}"}
         except Exception as e:
             out["secondary"] = {"error": f"{type(e).__name__}: {e}"}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.critic, args)
         if "secondary" in out and "error" not in out["secondary"]:
-            out["secondary"]["cpu_baseline"] = cpu_baseline("concat_mlp" if args.critic == "bilinear" else "bilinear", args)
+            other = "concat_mlp" if args.critic == "bilinear" else "bilinear"
+            out["secondary"]["cpu_baseline"] = cpu_baseline(other, args, dim=768 if other == "concat_mlp" else None)
     if rank == 0:  # the line first: a tear-down problem must not cost the measurement
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())

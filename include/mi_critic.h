@@ -82,7 +82,14 @@ typedef struct mi_stats {
   int64_t reserved2, reserved3;
 } mi_stats;
 
-int mi_abi_version(void);  /* 3: mi_bilinear_step added */
+/* Kernel paths reported by mi_bilinear_path / mi_separable_path (host-side queries; nothing is launched) */
+#define MI_PATH_GENERIC 0    /* strided-operand kernels of mi_gemm.h (fp32 parity mode, odd shapes)            */
+#define MI_PATH_GEMMS 1      /* 16-bit GEMM chain with G / G^T materialised (widths outside the fused kernel) */
+#define MI_PATH_FUSED 2      /* fused B x B kernel + the three-launch backward tail                          */
+#define MI_PATH_FUSED_TAIL 3 /* fused B x B kernel + the two-launch tail (the four-launch step)              */
+#define MI_PATH_FP8_GEMMS 4  /* fp8 forward products + bf16 backward chain                                   */
+
+int mi_abi_version(void);  /* 4: bf16 / fp16 boundary, path queries, MI_PREC_F16 / MI_PREC_F16X3 */
 const char* mi_last_error(void);
 
 /* Optional per-kernel timing (bench.py's roofline leg): between mi_profile_begin and mi_profile_end every kernel
@@ -191,6 +198,11 @@ int mi_bilinear_step(const float* x, const float* y, const float* w, const int64
                      int64_t d_txt, int estimator, int precision, const float* grad_out, float* loss_out,
                      mi_stats* stats, float* partials_out, float* grad_x, float* grad_y, float* grad_w, void* workspace,
                      size_t workspace_bytes, void* stream);
+
+/* Which kernels a shape takes: one of MI_PATH_* (or a negative MI_E* code).  Host-side arithmetic on the plan only; the
+ * Python binding uses it to warn once per shape when a 16-bit call leaves the fused kernels. */
+int mi_bilinear_path(int64_t b_rows, int64_t b, int64_t d_img, int64_t d_txt, int precision);
+int mi_separable_path(int64_t b_rows, int64_t b, int64_t d_img, int64_t d_txt, int64_t d_proj, int precision);
 
 /* ---- fused separable critic: S = (X Wg)(Y Wh)^T, bound, all gradients ------------------------------- */
 /* BASELINE.json configs[1] (an extension: the reference has no separable critic; bound, masking and pair semantics are

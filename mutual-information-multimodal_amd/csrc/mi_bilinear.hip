@@ -236,8 +236,12 @@ static int bilinear_tail(int64_t br, int64_t b, int64_t row_offset, int64_t dx, 
   }
   ta.w_frag = p.wfb;
   ta.dx = dx;
-  static const bool diag_no_dx = getenv("MI_TAIL_DIAG_NO_DX") != nullptr;  // timing experiment (wrong grad_x / grad_w)
+#ifdef MI_STAMPS  // diagnostic library only (make STAMPS=1): a timing experiment that leaves grad_x / grad_w wrong
+  static const bool diag_no_dx = getenv("MI_TAIL_DIAG_NO_DX") != nullptr;
   ta.grad_x = diag_no_dx ? nullptr : grad_x;
+#else
+  ta.grad_x = grad_x;
+#endif
   ta.dtt_frag = p.dttfb;
   int rc = launch_flash_tail(ta, dy, p.fl.slab_f16, merge != nullptr, st,
                              merge ? "bilinear sums -> loss, dT, dY | dX = dT W^T" : "bilinear sums -> dT, dY | dX = dT W^T");
@@ -789,6 +793,19 @@ int mi_bilinear_step(const float* x, const float* y, const float* w, const int64
                          workspace, workspace_bytes, 1, stream);
 }
 
+/* Which kernels a bilinear-critic shape takes (host-side arithmetic only, nothing is launched): MI_PATH_*.  The Python
+ * binding warns once per shape when a 16-bit call leaves the fused kernels. */
+int mi_bilinear_path(int64_t b_rows, int64_t b, int64_t d_img, int64_t d_txt, int precision) {
+  if (b_rows <= 0 || b <= 0 || d_img <= 0 || d_txt <= 0) return MI_EINVAL;
+  if (precision == MI_PREC_FP8) return fp8_ok(b_rows, b, d_img, d_txt, precision, true) ? MI_PATH_FP8_GEMMS : MI_ESHAPE;
+  if (!fast_ok(b_rows, b, d_img, d_txt, precision, true)) return MI_PATH_GENERIC;
+  char* fake = reinterpret_cast<char*>(uintptr_t(1) << 20);
+  Workspace ws(fake, ~size_t(0) >> 1);
+  BilinearPlan p = plan_bilinear(ws, b_rows, b, d_img, d_txt, precision);
+  if (!p.fl.ok) return MI_PATH_GEMMS;
+  return p.tail ? MI_PATH_FUSED_TAIL : MI_PATH_FUSED;
+}
+
 }  // extern "C"
 
 // ================================================================================================ separable critic
@@ -1073,6 +1090,13 @@ int mi_separable_bwd(const float* x, const float* y, const float* wg, const floa
 }
 
 }  // extern "C"
+
+extern "C" int mi_separable_path(int64_t b_rows, int64_t b, int64_t d_img, int64_t d_txt, int64_t d_proj, int precision) {
+  if (b_rows <= 0 || b <= 0 || d_img <= 0 || d_txt <= 0 || d_proj <= 0) return MI_EINVAL;
+  char* fake = reinterpret_cast<char*>(uintptr_t(1) << 20);
+  mi::Workspace ws(fake, ~size_t(0) >> 1);
+  return mi::plan_separable(ws, b_rows, b, d_img, d_txt, d_proj, precision).fast ? MI_PATH_FUSED : MI_PATH_GENERIC;
+}
 
 #ifdef MI_STAMPS
 // diagnostic build only: where the stamped kernels of this translation unit write their s_memtime values

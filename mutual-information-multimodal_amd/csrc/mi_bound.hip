@@ -284,7 +284,7 @@ using namespace mi;
 
 extern "C" {
 
-int mi_abi_version(void) { return 3; }
+int mi_abi_version(void) { return 4; }
 
 int mi_profile_begin(void) {
   for (auto& e : mi::g_prof) {

@@ -66,6 +66,8 @@ SIGNATURES = {
     "mi_bilinear_prep_local": (c_int, [_P, _P, _I64, _I64, _I64, _I64, _I, _P, _SZ, _P]),
     "mi_bilinear_fp8_stage": (c_int, [_P, _P, _P, _I64, _I64, _I64, _I64, _I, _P, _P, _SZ, _P]),
     "mi_bilinear_step": (c_int, [_P, _P, _P, _P, _I64, _I64, _I64, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _SZ, _P]),
+    "mi_bilinear_path": (c_int, [_I64, _I64, _I64, _I64, _I]),
+    "mi_separable_path": (c_int, [_I64, _I64, _I64, _I64, _I64, _I]),
     "mi_separable_workspace_bytes": (_SZ, [_I64, _I64, _I64, _I64, _I64, _I]),
     "mi_separable_fwd": (c_int, [_P] * 6 + [_I64] * 6 + [_I, _I, _I] + [_P] * 4 + [_SZ, _P]),
     "mi_separable_bwd": (c_int, [_P] * 6 + [_I64] * 6 + [_I] + [_P] * 7 + [_SZ, _I, _P]),
@@ -101,6 +103,27 @@ def load() -> ctypes.CDLL:
         fn.argtypes = args
     _lib = lib
     return lib
+
+
+MI_PATH_GENERIC, MI_PATH_GEMMS, MI_PATH_FUSED, MI_PATH_FUSED_TAIL, MI_PATH_FP8_GEMMS = 0, 1, 2, 3, 4
+PATH_NAMES = {0: "generic strided-operand kernels", 1: "16-bit GEMM chain with G / G^T through HBM",
+              2: "fused B x B kernel, three-launch tail", 3: "fused B x B kernel, two-launch tail", 4: "fp8 GEMM chain"}
+_warned_paths = set()
+
+
+def note_path(kind: str, shape: tuple, precision: int) -> int:
+    """The kernel path a shape takes (MI_PATH_*), with ONE logging.warning per (critic, shape, precision) when a 16-bit
+    call leaves the fused kernels: such shapes are correct but 2 - 3 times slower and move G / G^T through HBM."""
+    lib = load()
+    path = lib.mi_bilinear_path(*shape, precision) if kind == "bilinear" else lib.mi_separable_path(*shape, precision)
+    key = (kind, tuple(shape), precision)
+    if precision in (MI_PREC_BF16,) and 0 <= path < MI_PATH_FUSED and key not in _warned_paths:
+        _warned_paths.add(key)
+        import logging
+        logging.getLogger("mutual_info_img_txt").warning(
+            "%s critic, shape (b_rows, b, widths) = %s: outside the fused B x B kernel (needs batch %% 32 == 0 and a "
+            "score width in {128, 256, 512, 768, 1024}); running the %s", kind, tuple(shape), PATH_NAMES.get(path, path))
+    return path
 
 
 def check(rc: int, what: str) -> None:

@@ -388,6 +388,16 @@ class GlobalBatchCriticFn(torch.autograd.Function):
         return (None, None, None, None, None, gx, gy, *gparams)
 
 
+def _sharded_precision(precision: str, critic: str, x, y) -> int:
+    """The same name -> code resolution as on one GPU (_hip.resolve_precision): "f32" on the bilinear critic is the bf16x3
+    scheme where every size is a multiple of 8 (fp32 tolerances at a sixth of the time), exact fp32 products otherwise and
+    under "f32_exact" -- so that a precision name means the same numerics and speed on one GPU and on a sharded batch."""
+    from .mi_critics import _precision_code
+    if critic == "bilinear" and x.dim() == 2 and y.dim() == 2:
+        return _hip.resolve_precision(precision, True, (x.shape[0], x.shape[1], y.shape[1]))
+    return _precision_code(precision)
+
+
 def global_batch_mi_bound(embedding_img, embedding_txt, study_id_codes, critic_params: Sequence[torch.Tensor],
                           estimator: str = "infonce", precision: str = "bf16", critic: str = "bilinear", group=None,
                           ops=None, return_stats: bool = False):
@@ -399,7 +409,7 @@ def global_batch_mi_bound(embedding_img, embedding_txt, study_id_codes, critic_p
     if ops is None:
         ops = {"bilinear": HipBilinearOps, "separable": HipSeparableOps, "concat_mlp": HipConcatMlpOps}[critic]()
     est = _estimator_code(estimator)
-    prec = _precision_code(precision)
+    prec = _sharded_precision(precision, critic, embedding_img, embedding_txt)
     loss, stats = GlobalBatchCriticFn.apply(ops, group, est, prec, study_id_codes, embedding_img, embedding_txt,
                                             *critic_params)
     loss = loss if estimator == "dv" else loss.reshape(())
@@ -433,7 +443,7 @@ class GlobalBatchGraphStep:
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
         self.ops = ops if ops is not None else {"bilinear": HipBilinearOps, "separable": HipSeparableOps, "concat_mlp": HipConcatMlpOps}[critic]()
-        self.est, self.prec = _estimator_code(estimator), _precision_code(precision)
+        self.est, self.prec = _estimator_code(estimator), _sharded_precision(precision, critic, x, y)
         self.x, self.y, self.sid = x.detach(), y.detach(), sid
         self.params = [p.detach() for p in params]
         for t in (self.x, self.y, self.sid, *self.params):
@@ -492,6 +502,8 @@ class GlobalBatchGraphStep:
             self.graph_full = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph_full):
                 self._whole_step()
+            self._remember_captured()
+            self._captured["grad_y"] = self.grad_y
             return
         pool = torch.cuda.graph_pool_handle()
         if self._has_local:
@@ -510,6 +522,19 @@ class GlobalBatchGraphStep:
         self.graph_bwd = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph_bwd, pool=pool):
             self._merge_backward()
+        self._remember_captured()
+
+    _CAPTURED_ATTRS = ("record", "saved", "loss", "stats", "grad_x", "grad_y_partial")
+
+    def _remember_captured(self):
+        """The tensors the graphs read and write.  step_eager() on this object rebinds record / saved / loss ... to a
+        fresh eager workspace; a later replay must gather and return the CAPTURED ones again (in raw-record
+        mode the backward graph otherwise merged the records of an older forward)."""
+        self._captured = {k: getattr(self, k) for k in self._CAPTURED_ATTRS if hasattr(self, k)}
+
+    def _restore_captured(self):
+        for k, v in getattr(self, "_captured", {}).items():
+            setattr(self, k, v)
 
     def _prep_local(self):
         if self._has_local:
@@ -588,10 +613,12 @@ class GlobalBatchGraphStep:
         """all-gather Y, ids | local forward | all-gather records | merge + local backward | reduce-scatter dY, ONE
         all-reduce of the flat parameter-gradient buffer.  Five collectives per step, in this order on every rank."""
         if self.graph_full is not None:
+            self._restore_captured()
             self.graph_full.replay()
             return self.loss
         if self.graph_fwd is None:
             return self.step_eager()
+        self._restore_captured()
         self._gather_inputs()
         self.graph_fwd.replay()
         self._gather_records()

@@ -71,11 +71,15 @@ class GraphedMiStep:
         self.grad_x = torch.zeros_like(self.x)
         self.grad_y = torch.zeros_like(self.y)
         self.grad_params = [torch.zeros_like(p) for p in self.params]
+        self.path = None
         if self.kind == "bilinear":
+            if self.params:
+                self.path = _hip.note_path("bilinear", (self.b, self.b, self.dx, self.dy), self.prec)
             nbytes = self.lib.mi_bilinear_workspace_bytes(self.b, self.b, self.dx, self.dy, self.prec)
         elif self.kind == "separable":
             if tuple(self.params[0].shape) != (self.dx, self.k) or tuple(self.params[1].shape) != (self.dy, self.k):
                 raise ValueError("projection shapes must be [d_img, d_proj] and [d_txt, d_proj]")
+            self.path = _hip.note_path("separable", (self.b, self.b, self.dx, self.dy, self.k), self.prec)
             nbytes = self.lib.mi_separable_workspace_bytes(self.b, self.b, self.dx, self.dy, self.k, self.prec)
         else:
             self.h1, self.h2 = self.params[0].shape[0], self.params[2].shape[0]

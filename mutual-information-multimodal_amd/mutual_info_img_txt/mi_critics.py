@@ -167,6 +167,8 @@ class BilinearCriticFn(torch.autograd.Function):
         b, dx = x.shape
         dy = y.shape[1]
         dev = x.device
+        if w is not None:
+            _hip.note_path("bilinear", (b, b, dx, dy), precision)
         ws = _hip.workspace(lib.mi_bilinear_workspace_bytes(b, b, dx, dy, precision), dev)
         stats = _hip.new_stats(dev)
         loss = torch.empty(1, dtype=torch.float32, device=dev)
@@ -214,6 +216,7 @@ class SeparableCriticFn(torch.autograd.Function):
         if wg.shape[0] != dx or wh.shape != (dy, k):
             raise ValueError("projection shapes must be [d_img, d_proj] and [d_txt, d_proj]")
         dev = x.device
+        _hip.note_path("separable", (b, b, dx, dy, k), precision)
         ws = _hip.workspace(lib.mi_separable_workspace_bytes(b, b, dx, dy, k, precision), dev)
         stats = _hip.new_stats(dev)
         loss = torch.empty(1, dtype=torch.float32, device=dev)

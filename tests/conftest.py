@@ -15,6 +15,7 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "slow: minutes of host-side oracle work (MI_SKIP_SLOW=1 skips these)")
 
 
 def _gpu_available():

@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol(lib):
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/mi_critic.h but not exported"
     assert sorted(_hip.SIGNATURES) == declared, "ctypes signature table out of sync with the header"
-    assert lib.mi_abi_version() == 3
+    assert lib.mi_abi_version() == 4
 
 
 def test_workspace_queries_are_host_only(lib):
@@ -113,3 +113,22 @@ def test_make_mlp_matches_reference_structure(golden):
     assert [type(m).__name__ for m in mlp] == list(g["kinds"])
     assert list(mlp.state_dict().keys()) == list(g["keys"])
     assert [str(tuple(v.shape)) for v in mlp.state_dict().values()] == list(g["shapes"])
+
+
+def test_path_queries(lib, caplog):
+    """mi_bilinear_path / mi_separable_path are host-only; the binding warns ONCE per shape that leaves the fused kernels."""
+    import logging
+    from mutual_info_img_txt import _hip
+    assert lib.mi_bilinear_path(4096, 4096, 512, 512, _hip.MI_PREC_BF16) == _hip.MI_PATH_FUSED_TAIL
+    assert lib.mi_bilinear_path(4096, 4096, 512, 512, _hip.MI_PREC_F32) == _hip.MI_PATH_GENERIC
+    assert lib.mi_bilinear_path(4096, 4096, 512, 512, _hip.MI_PREC_BF16X3) == _hip.MI_PATH_GEMMS
+    assert lib.mi_bilinear_path(8192, 8192, 1024, 1024, _hip.MI_PREC_FP8) == _hip.MI_PATH_FP8_GEMMS
+    assert lib.mi_bilinear_path(4000, 4000, 520, 520, _hip.MI_PREC_BF16) == _hip.MI_PATH_GEMMS    # width outside the fused kernel
+    assert lib.mi_bilinear_path(0, 4096, 512, 512, 1) == -1
+    assert lib.mi_separable_path(256, 256, 256, 256, 256, _hip.MI_PREC_BF16) >= _hip.MI_PATH_FUSED
+    with caplog.at_level(logging.WARNING, logger="mutual_info_img_txt"):
+        _hip._warned_paths.clear()
+        assert _hip.note_path("bilinear", (4000, 4000, 520, 520), _hip.MI_PREC_BF16) == _hip.MI_PATH_GEMMS
+        assert _hip.note_path("bilinear", (4000, 4000, 520, 520), _hip.MI_PREC_BF16) == _hip.MI_PATH_GEMMS
+        assert _hip.note_path("bilinear", (4096, 4096, 512, 512), _hip.MI_PREC_BF16) == _hip.MI_PATH_FUSED_TAIL
+    assert sum("outside the fused" in r.getMessage() for r in caplog.records) == 1

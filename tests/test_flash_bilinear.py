@@ -117,10 +117,60 @@ def test_flash_reference_point_rescale(dev):
     o = orc.bilinear_step_rounded(x, y, w, sid, "infonce")
     s = o["scores"]
     early = float(s[:, :32][orc.negative_mask(sid)[:, :32]].max())
-    assert float(s.max()) - early > 30.0, "the case must cross the rescale threshold"
+    assert float(s.max()) - early > 60.0, "the case must cross the rescale threshold (kFlThr = 60)"
     assert abs(float(loss) - float(o["loss"])) < 2e-3 * float(s.abs().max())
     for name, got, ref in (("dx", gx, o["dx"]), ("dy", gy, o["dy"]), ("dw", gw, o["dw"])):
         assert _rel(got, ref) < 1e-2, name
+
+
+@pytest.mark.parametrize("G", [1, 4])
+def test_flash_trained_critic_distribution(dev, G):
+    """The score distribution of a TRAINED critic: every diagonal positive lies more than kFlThr = 60 above
+    every negative, a few ids are duplicated (those pairs are dropped, neither positive nor negative) and the FIRST
+    streamed tile of most waves is a masked one (the diagonal tile, or one holding duplicates).  The unmasked maximum of
+    such a tile would raise the reference point by > 60: both fix_masked_tile paths (the in-place masking and the full
+    redo with a second decision) and a pending f_pend rescale are exercised.  Checked against the rounded fp64 oracle on
+    the whole batch (G = 1) and as four row blocks merged in block order (G = 4)."""
+    from mutual_info_img_txt import _hip
+    from mutual_info_img_txt.distributed import HipBilinearOps
+    b, d = 512, 256
+    gen = torch.Generator().manual_seed(23)
+    y = torch.randn(b, d, generator=gen)
+    y = y / y.norm(dim=1, keepdim=True)
+    x = y + 0.05 * torch.randn(b, d, generator=gen)      # image i matches text i
+    w = torch.eye(d) * 150.0                             # positives ~ 150, negatives ~ 150 * cos(random) within +-56
+    sid = torch.arange(b)
+    for i in (0, 1, 2, 33, 64, 65, 300):                 # duplicates inside the first tile, inside a later one, far apart
+        sid[i + 100 if i == 300 else i + 1] = sid[i]
+    o = orc.bilinear_step_rounded(x, y, w, sid, "infonce")
+    s, neg = o["scores"], orc.negative_mask(sid)
+    assert float(torch.diagonal(s).min()) - float(s[neg].max()) > 60.0, "positives must clear every negative by kFlThr"
+    if G == 1:
+        loss, st, gx, gy, gw = _run(dev, x, y, w, sid, "infonce")
+        assert st["n_neg"] == int(neg.sum())
+    else:
+        ops = HipBilinearOps()
+        xd, yd, wd, sd = x.to(dev), y.to(dev), w.to(dev), sid.to(dev)
+        br = b // G
+        recs, saved = [], []
+        for g in range(G):
+            rec, sv = ops.forward(xd[g * br:(g + 1) * br].contiguous(), yd, [wd], sd[g * br:(g + 1) * br].contiguous(), sd,
+                                  g * br, 1, 1, True)
+            recs.append(rec)
+            saved.append(sv)
+        loss, stats = ops.merge(torch.stack(recs), b, 1)
+        go = torch.ones(1, device=dev)
+        gx, gy, gw = torch.empty_like(xd), torch.zeros_like(yd), torch.zeros_like(wd)
+        for g in range(G):
+            a, c, (e,) = ops.backward(saved[g], stats, go)
+            gx[g * br:(g + 1) * br] = a
+            gy += c
+            gw += e
+        assert _hip.stats_dict(stats)["n_neg"] == int(neg.sum())
+        loss, gx, gy, gw = loss.cpu(), gx.cpu(), gy.cpu(), gw.cpu()
+    assert abs(float(loss.sum()) - float(o["loss"])) < 2e-3 * float(s.abs().max())
+    for name, got, ref in (("dx", gx, o["dx"]), ("dy", gy, o["dy"]), ("dw", gw, o["dw"])):
+        assert _rel(got, ref) < 1e-2, (name, _rel(got, ref))
 
 
 def test_flash_no_negatives_and_single_block(dev):

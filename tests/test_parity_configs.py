@@ -210,9 +210,16 @@ def _concat_all_grads(dev, x, y, sid, params, hidden, est, precision):
 # B > 1024 makes plan_concat split rows over workgroups (rows_per_msplit > 1, rows_per_dsplit > 16, several i-blocks
 # and j-splits): the multi-row paths of the db2 / dw2 / finish_w2 / dV-slab / split-K dW1 kernels, with small widths so
 # that the fp64 oracle stays cheap.  And the reference's own widths (h = 1024 / 512) at B = 512, d = 768.
-@pytest.mark.parametrize("b,d,h1,h2,rb", [(1536, 32, 64, 256, 128), (2048, 32, 64, 256, 128), (512, 768, 1024, 512, 64)])
+#
+# The last case is BASELINE config 4's own size (B = 4096, d = 512, h = 1024 / 512: 16.8 M pairs): all eight gradients of
+# the 16-bit kernels against the rounded oracle, row-blocked.  The oracle needs ~106 TFLOP of fp64
+# work on the host (a few minutes on the box's 16 cores): marked `slow`, skipped with MI_SKIP_SLOW=1.
+@pytest.mark.parametrize("b,d,h1,h2,rb", [(1536, 32, 64, 256, 128), (2048, 32, 64, 256, 128), (512, 768, 1024, 512, 64),
+                                          pytest.param(4096, 512, 1024, 512, 16, marks=pytest.mark.slow)])
 @pytest.mark.parametrize("precision", ["f32", "bf16"])
 def test_concat_all_gradients_at_size(dev, b, d, h1, h2, rb, precision):
+    if b >= 4096 and (precision == "f32" or os.environ.get("MI_SKIP_SLOW")):
+        pytest.skip("full-size case: 16-bit modes only (the fp32 kernels are covered up to B = 2048); MI_SKIP_SLOW skips it")
     x, y, _, params = orc.synthetic_case(b, d, d, h1=h1, h2=h2, salt=b // 8)
     sid = _dup_ids(b)
     loss, grads = _concat_all_grads(dev, x, y, sid, params, (h1, h2), "dv", precision)

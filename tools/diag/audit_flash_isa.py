@@ -17,6 +17,16 @@ every bilinear_flash_kernel instantiation:
     an output, hipcc pads a wait state between any two consecutive asm statements of a chain -- so nothing but this
     check would notice a register copy slipped in between two of them.)
 
+  * the softmax micro-ops that overwrite a register they declare as an INPUT only (fl_v_exp, fl_v_add, fl_dpp_max: declared
+    that way so that hipcc pads no wait state between two of them) form intact chains:
+      - `v_exp_f32 vN, vN` exponentiates a register that the last asm `v_fmamk_f32` (the prescale) wrote, the `v_add_f32`
+        and `v_cvt_pk_bf16_f32` behind it read exactly that register, and NO compiler-generated instruction (a copy, a
+        spill, an accumulator move) reads or writes it between the prescale and its last asm reader;
+      - all running-sum additions between two `; fl_opaque` markers (fl_v_opaque: where hipcc is told the sum changed) use
+        one and the same accumulator register, untouched by compiler-generated instructions in between;
+      - the six `v_max_f32_dpp` steps of a wave maximum and the `v_readlane_b32` behind them name one register, untouched by
+        compiler-generated instructions from the first step to the read.
+
 Exit status 0 = clean.  Used by tests/test_flash_isa_audit.py (CPU suite) and by hand after kernel edits.
 """
 import os
@@ -43,9 +53,13 @@ def regs_of(text):
 
 
 def compile_asm():
+    if os.environ.get("MI_AUDIT_ASM"):  # reuse an assembly file (development)
+        return open(os.environ["MI_AUDIT_ASM"]).read()
     out = os.path.join(tempfile.mkdtemp(prefix="mi_audit_"), "mi_bilinear.s")
+    # extra compiler flags select a build variant: `audit_flash_isa.py -DMI_FL_WAIT_GROUP=4`, `-DMI_STAMPS -DMI_FL_DIAG=0`
     cmd = ["hipcc", "-O3", "-std=c++17", "-fPIC", "-fno-slp-vectorize", "--offload-arch=gfx950", "-S",
-           "--cuda-device-only", "-o", out, os.path.join(CSRC, "mi_bilinear.hip")]
+           "--cuda-device-only", *[a for a in sys.argv[1:] if a.startswith("-D")], "-o", out,
+           os.path.join(CSRC, "mi_bilinear.hip")]
     subprocess.run(cmd, check=True, stderr=subprocess.DEVNULL)
     with open(out) as f:
         return f.read()
@@ -66,12 +80,61 @@ def audit(name, body):
     in_asm = False
     m = re.search(r"ILi(\d+)E", name)
     chain_len = int(m.group(1)) // 16 if m else 0
+    grad = "ELb1E" in name  # bilinear_flash_kernel<D, GRAD>
     chain = None  # [destination registers, MFMAs seen]
+    hidden = {}       # VGPR -> "prescaled" | "exp": values asm statements rewrite behind hipcc's back
+    asm_block = []    # the instructions of the CURRENT asm statement
+    lsum_touch = None  # a compiler-generated instruction touched the running sum: fine only if an fl_opaque follows
+    vreg = lambda t: ("v", int(t[1:])) if re.fullmatch(r"v\d+", t.split()[0] if t else "") else None  # noqa: E731
+    lsum = None       # accumulator register of the running-sum additions since the last `; fl_opaque`
+    dpp = None        # [register, steps seen] of an open wave-maximum chain
     for ln, raw in enumerate(lines, 1):
         if "#ASMSTART" in raw:
             in_asm = True
+            asm_block = []
         elif "#ASMEND" in raw:
             in_asm = False
+            if len(asm_block) == 1:  # the micro-ops are one-instruction statements (an `s_nop` in front does not count)
+                bln, op, ops, operands, line = asm_block[0]
+                d = vreg(ops[0]) if ops else None
+                if op == "v_fmamk_f32" and d:
+                    hidden[d] = "prescaled"
+                elif op == "v_exp_f32" and d and len(ops) == 2 and vreg(ops[1]) == d:
+                    if hidden.get(d) == "prescaled":
+                        hidden[d] = "exp"
+                    else:
+                        problems.append(f"{name}:{bln}: `{line}` exponentiates a register no asm prescale wrote")
+                elif op == "v_add_f32" and d and len(ops) == 3 and vreg(ops[1]) == d:
+                    p = vreg(ops[2])
+                    if p is None or hidden.get(p) != "exp":
+                        problems.append(f"{name}:{bln}: `{line}` adds a register that is not a fresh asm exponential")
+                    if not grad:  # forward-only kernel: no output product, the addition is the exponential's last reader
+                        hidden.pop(p, None)
+                    if lsum is None:
+                        lsum = d
+                    elif d != lsum:
+                        problems.append(f"{name}:{bln}: `{line}`: the running sum moved from v{lsum[1]} to v{d[1]} between two fl_opaque points")
+                    if lsum_touch is not None:
+                        problems.append(f"{name}:{lsum_touch[0]}: compiler-generated `{lsum_touch[1]}` touches the running-sum "
+                                        f"register between two fl_opaque points")
+                        lsum_touch = None
+                elif op == "v_cvt_pk_bf16_f32" and len(ops) == 3:
+                    for src in (vreg(ops[1]), vreg(ops[2])):
+                        if src is None or hidden.get(src) != "exp":
+                            problems.append(f"{name}:{bln}: `{line}` packs a register that is not a fresh asm exponential")
+                        hidden.pop(src, None)
+                elif op == "v_max_f32_dpp" and d:
+                    if "quad_perm:[1,0,3,2]" in operands:
+                        if dpp is not None:
+                            problems.append(f"{name}:{bln}: a wave-maximum chain starts inside another")
+                        dpp = [d, 1]
+                    elif dpp is None or dpp[0] != d:
+                        problems.append(f"{name}:{bln}: `{line}` is not on the register of the open wave-maximum chain")
+                    else:
+                        dpp[1] += 1
+        elif in_asm and "fl_opaque" in raw:
+            lsum = None
+            lsum_touch = None
         elif not in_asm and re.search(r"\bm0\b", raw.split(";")[0]):
             problems.append(f"{name}:{ln}: compiler-generated use of M0: {raw.strip()}")
         line = raw.split(";")[0].strip() if not raw.strip().startswith(";") else ""
@@ -109,6 +172,25 @@ def audit(name, body):
                 chain = None
         else:
             touched = regs_of(operands)
+            ops = [o.strip() for o in operands.split(",")]
+            if not in_asm:
+                for r in touched:
+                    if hidden.get(r) == "exp":  # (a prescaled value is still what hipcc believes it is)
+                        problems.append(f"{name}:{ln}: compiler-generated `{line}` touches {r[0]}{r[1]}, which asm micro-ops "
+                                        f"rewrite behind hipcc's back (state: {hidden[r]})")
+                    if lsum is not None and r == lsum:
+                        lsum_touch = (ln, line)  # fine if an fl_opaque marker follows before the next hidden addition
+                    if dpp is not None and r == dpp[0]:
+                        problems.append(f"{name}:{ln}: compiler-generated `{line}` touches v{dpp[0][1]} inside a wave-maximum chain")
+            else:
+                if op != "s_nop":
+                    asm_block.append((ln, op, ops, operands, line))
+                d = vreg(ops[0]) if ops else None
+                if op == "v_readlane_b32" and dpp is not None:
+                    src = vreg(ops[1]) if len(ops) > 1 else None
+                    if src != dpp[0] or dpp[1] != 6:
+                        problems.append(f"{name}:{ln}: `{line}` reads v{src[1] if src else '?'} after {dpp[1]} steps on v{dpp[0][1]}")
+                    dpp = None
             for regs, age in inflight:
                 if age < WAIT_STATES and (regs & touched):
                     problems.append(f"{name}:{ln}: `{line}` touches the destination of an MFMA issued {age} wait states earlier")
