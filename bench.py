@@ -48,7 +48,8 @@ for _p in (ROOT, PKG):
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
-PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3,  # dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md
+PEAK_TFLOPS = {"bf16": 2500.0, "f16": 2500.0,  # fp16 MFMA runs at the bf16 rate (guide, Matrix cores)
+               "f32": 157.3,  # dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md
                "f32_exact": 157.3,       # v_mfma_f32_32x32x2_f32 products ("f32" on the bilinear critic runs bf16x3)
                "bf16x3": 2500.0 / 3,     # three bf16 MFMAs per algorithmic product
                "fp8": 5000.0}            # the dense fp8 peak: the forward products run on v_mfma_scale_f32_32x32x64_f8f6f4
@@ -56,7 +57,7 @@ PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3,  # dense MFMA peaks, /opt/skills/gu
 PEAK_HBM_GBS = 8000.0
 # the secondary leg (the reference's concat-MLP critic): fast 16-bit modes, the first one is the `secondary` number; and
 # the modes that hold the fp32 tolerances
-SECONDARY_FAST = {"concat_mlp": ["bf16"]}
+SECONDARY_FAST = {"concat_mlp": ["f16", "bf16"]}
 SECONDARY_PARITY = ["f32"]
 
 
@@ -69,7 +70,7 @@ def parse_args():
     p.add_argument("--dim", type=int, default=512)
     p.add_argument("--critic", default="bilinear", choices=["bilinear", "concat_mlp"])
     p.add_argument("--estimator", default="infonce", choices=["dv", "infonce"])
-    p.add_argument("--precision", default="bf16", choices=["bf16", "f32", "f32_exact", "bf16x3", "fp8"])
+    p.add_argument("--precision", default="bf16", choices=["bf16", "f32", "f32_exact", "bf16x3", "fp8", "f16"])
     p.add_argument("--graph", default="auto", choices=["auto", "on", "off", "full"],
                    help="on: replay the step from a hipGraph (one GPU: GraphedMiStep; N GPUs: the two compute sections "
                         "are graphs, the RCCL collectives stay eager between them).  off: the same C-ABI calls issued one "

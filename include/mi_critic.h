@@ -42,7 +42,10 @@
  *            MI_PREC_FP8 = 3 (bilinear critic with a weight matrix only; widths multiples of 16: x, y, W and T = x W are
  *            quantised to OCP e4m3 with per-tensor scales absmax / 448 computed on the device, both forward products
  *            run on the fp8 MFMA with fp32 accumulation, the backward is straight-through on the quantised values
- *            with bf16 MFMA operands; other entry points reject it).
+ *            with bf16 MFMA operands; other entry points reject it),
+ *            MI_PREC_F16 = 4 (concat-MLP critic only: fp16 MFMA operands -- U, V, W2 and w3 W2 scaled by powers of two
+ *            derived on the device from their absmax, the generated operand relu(U_i + V_j) formed by packed fp16
+ *            arithmetic -- fp32 accumulate; the fast mode of the reference's critic, csrc/mi_concat_f16.h).
  */
 #ifndef MI_CRITIC_H
 #define MI_CRITIC_H
@@ -67,6 +70,8 @@ extern "C" {
 #define MI_PREC_BF16 1
 #define MI_PREC_BF16X3 2
 #define MI_PREC_FP8 3
+#define MI_PREC_F16 4   /* concat-MLP critic: fp16 MFMA operands with power-of-two tensor scales, fp32 accumulate */
+#define MI_PREC_F16X3 5 /* concat-MLP critic: every operand as two fp16 parts, three MFMAs per product (fp32 tolerances) */
 
 /* Statistics block written by every forward call and read by the matching backward call (64 bytes). */
 typedef struct mi_stats {

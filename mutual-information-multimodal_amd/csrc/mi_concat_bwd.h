@@ -46,6 +46,48 @@ __global__ void prep_w2w_kernel(const float* __restrict__ w2, const float* __res
   }
 }
 
+// ---- fp16 mode (MI_PREC_F16, mi_concat_f16.h): power-of-two operand scales derived on the device from absmax slots ----
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+struct F16Scales {
+  unsigned amax_bits[4];  // bit patterns of max|U|, max|V|, max|W2|, max|w3| (non-negative floats order as unsigned)
+};
+constexpr float kF16GScale = 4096.0f;  // s_g: |g| <= 1 for grad_out = 1; grad_out is applied to the finished sums
+// 2^e with 2^e * a in [2^lo_exp, 2^(lo_exp + 1)) for finite a > 0; 1 otherwise.  A pure function of the bits: every
+// kernel derives the same scale from the same absmax slots.
+__device__ __forceinline__ float f16_pow2_scale(float a, int lo_exp) {
+  if (!(a > 0.0f) || !(a < __builtin_inff())) return 1.0f;
+  int e;
+  (void)frexpf(a, &e);  // a = m 2^e, m in [0.5, 1)
+  return ldexpf(1.0f, lo_exp + 1 - e);
+}
+struct F16ScaleSet {
+  float s_uv, s_w, s_ww;
+};
+__device__ __forceinline__ F16ScaleSet f16_scales(const F16Scales* sc) {
+  const float au = __uint_as_float(sc->amax_bits[0]), av = __uint_as_float(sc->amax_bits[1]);
+  const float aw = __uint_as_float(sc->amax_bits[2]), a3 = __uint_as_float(sc->amax_bits[3]);
+  F16ScaleSet r;
+  r.s_uv = f16_pow2_scale(au + av, -2);  // (max|U| + max|V|) s in [1/4, 1/2): the clamp at 1 is never reached
+  r.s_w = f16_pow2_scale(aw, 13);
+  r.s_ww = f16_pow2_scale(aw * a3, 13);
+  return r;
+}
+// 16-bit operand traits of the bit-expanding kernels
+template <typename OpT>
+struct Op16 {
+  using Vec8 = bf16x8;
+};
+template <>
+struct Op16<f16_t> {
+  using Vec8 = f16x8;
+};
+__device__ __forceinline__ f32x16 mfma16(const bf16x8& a, const bf16x8& b, const f32x16& c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x16 mfma16(const f16x8& a, const f16x8& b, const f32x16& c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+
 // ================================================================================================= duv kernel
 template <typename OpT>
 struct DuvCfg;
@@ -56,6 +98,8 @@ struct DuvCfg<bf16_t> {
   static constexpr int PADW = 8;  // row pad of the LDS weight slice in elements (1040-byte rows: conflict-free b128)
 };
 template <>
+struct DuvCfg<f16_t> : DuvCfg<bf16_t> {};
+template <>
 struct DuvCfg<float> {
   static constexpr int KC = 32;
   static constexpr int NT = 1;
@@ -65,22 +109,26 @@ struct DuvCfg<float> {
 constexpr int kDuvTI = 64;  // image rows per workgroup
 constexpr int kDuvTJ = 8;   // text columns per step
 
-template <typename OpT>
+// UvT: element type of U / V (fp32; fp16 in the fp16 mode, where relu' of layer 1 must be decided on the very values the
+// forward added).  sc != null (fp16 mode): W2wP carries the scale s_ww, undone through g.
+template <typename OpT, typename UvT = float>
 __global__ __launch_bounds__(512) void concat_bwd_duv_kernel(
-    const float* __restrict__ U, const float* __restrict__ V, const OpT* __restrict__ W2wP,
+    const UvT* __restrict__ U, const UvT* __restrict__ V, const OpT* __restrict__ W2wP,
     const unsigned long long* __restrict__ bitsP, const float* __restrict__ S, const int64_t* __restrict__ sid_rows,
     const int64_t* __restrict__ sid_cols, const mi_stats* __restrict__ stats, const float* __restrict__ grad_out,
     int64_t b_rows, int64_t b, int64_t row_offset, int H1, int H2, int cols_per_split, int natural_order,
-    float* __restrict__ dUslab /* [n_jsplit][b_rows][H1] */, float* __restrict__ dVslab /* [n_iblk][b][H1] */) {
+    float* __restrict__ dUslab /* [n_jsplit][b_rows][H1] */, float* __restrict__ dVslab /* [n_iblk][b][H1] */,
+    const F16Scales* __restrict__ sc = nullptr) {
   using Cfg = DuvCfg<OpT>;
+  using Vec8 = typename Op16<OpT>::Vec8;
   constexpr int KC = Cfg::KC, NT = Cfg::NT;
   constexpr bool kBf16 = sizeof(OpT) == 2;
   const int LDW = H2 + Cfg::PADW;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   OpT* wt = reinterpret_cast<OpT*>(smem_raw);                                   // [KC][LDW]
   size_t off = (((size_t)KC * LDW * sizeof(OpT)) + 15) & ~(size_t)15;
-  bf16x8* lut = reinterpret_cast<bf16x8*>(smem_raw + off);                      // [256] (bf16 only)
-  off += 256 * sizeof(bf16x8);
+  Vec8* lut = reinterpret_cast<Vec8*>(smem_raw + off);                          // [256] (16-bit modes only)
+  off += 256 * sizeof(Vec8);
   float* gs = reinterpret_cast<float*>(smem_raw + off);                         // [64][8]
   off += kDuvTI * kDuvTJ * sizeof(float);
   float* vneg = reinterpret_cast<float*>(smem_raw + off);                       // [8][KC]
@@ -105,7 +153,8 @@ __global__ __launch_bounds__(512) void concat_bwd_duv_kernel(
   const float go = grad_out ? grad_out[0] : 1.0f;
   const float lse = stats->lse;
   const float gpos = -go / (float)stats->n_pos;
-  const float gscale = kBf16 ? 0.5f : 1.0f;  // the bf16 fragment table holds 2.0 for a set bit
+  float gscale = kBf16 ? 0.5f : 1.0f;  // the 16-bit fragment table holds 2.0 for a set bit
+  if (sc) gscale /= f16_scales(sc).s_ww;
 
   // ---- one-time setup: weight slice, table, U registers ----------------------------------------------------------
   {
@@ -127,9 +176,9 @@ __global__ __launch_bounds__(512) void concat_bwd_duv_kernel(
     }
     if constexpr (kBf16) {
       if (tid < 256) {
-        bf16x8 f;
+        Vec8 f;
 #pragma unroll
-        for (int q = 0; q < 8; ++q) f[q] = (bf16_t)(((tid >> q) & 1) ? 2.0f : 0.0f);
+        for (int q = 0; q < 8; ++q) f[q] = (OpT)(((tid >> q) & 1) ? 2.0f : 0.0f);
         lut[tid] = f;
       }
     }
@@ -145,7 +194,7 @@ __global__ __launch_bounds__(512) void concat_bwd_duv_kernel(
 #pragma unroll
       for (int ct = 0; ct < NT; ++ct) {
         const int k = kc0 + 32 * ct + c;
-        ureg[m][is][ct] = (k < H1) ? U[li * H1 + k] : 0.0f;
+        ureg[m][is][ct] = (k < H1) ? (float)U[li * H1 + k] : 0.0f;
         duacc[m][is][ct] = 0.0f;
       }
     }
@@ -174,7 +223,7 @@ __global__ __launch_bounds__(512) void concat_bwd_duv_kernel(
         const int jl2 = e / KC, kk = e % KC;
         int64_t gj2 = j + jl2;
         if (gj2 >= b) gj2 = b - 1;
-        vneg[e] = (kc0 + kk < H1) ? -V[gj2 * H1 + kc0 + kk] : 0.0f;
+        vneg[e] = (kc0 + kk < H1) ? -(float)V[gj2 * H1 + kc0 + kk] : 0.0f;
       }
     }
     __syncthreads();
@@ -194,15 +243,14 @@ __global__ __launch_bounds__(512) void concat_bwd_duv_kernel(
         if constexpr (kBf16) {
 #pragma unroll
           for (int s = 0; s < 8; ++s) {
-            bf16x8 af[2];
+            Vec8 af[2];
 #pragma unroll
             for (int m = 0; m < 2; ++m) af[m] = lut[(unsigned)(words[m][pw] >> (8 * s)) & 0xFFu];
 #pragma unroll
             for (int ct = 0; ct < NT; ++ct) {
-              const bf16x8 bfr = *reinterpret_cast<const bf16x8*>(&wt[(32 * ct + c) * LDW + (pw * 2 + h) * 64 + 8 * s]);
+              const Vec8 bfr = *reinterpret_cast<const Vec8*>(&wt[(32 * ct + c) * LDW + (pw * 2 + h) * 64 + 8 * s]);
 #pragma unroll
-              for (int m = 0; m < 2; ++m)
-                acc[m][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[m], bfr, acc[m][ct], 0, 0, 0);
+              for (int m = 0; m < 2; ++m) acc[m][ct] = mfma16(af[m], bfr, acc[m][ct]);
             }
           }
         } else {
@@ -526,14 +574,20 @@ __global__ __launch_bounds__(256) void concat_bwd_finish_w2_kernel(const float* 
                                                                    const float* __restrict__ w2, const float* __restrict__ b2,
                                                                    const float* __restrict__ w3, int H1, int H2,
                                                                    float* __restrict__ dW2, float* __restrict__ dW3,
-                                                                   float* __restrict__ db2, float* __restrict__ db3) {
+                                                                   float* __restrict__ db2, float* __restrict__ db3,
+                                                                   const F16Scales* __restrict__ sc = nullptr,
+                                                                   const float* __restrict__ grad_out = nullptr) {
   __shared__ float red[4];
   const int n = blockIdx.x, tid = threadIdx.x;
   const float w3n = w3[n];
+  // fp16 mode: the slabs hold 2 s_uv s_g D computed for grad_out = 1 (mi_concat_f16.h)
+  float dscale = 1.0f;
+  if (sc) dscale = (grad_out ? grad_out[0] : 1.0f) / (2.0f * kF16GScale * f16_scales(sc).s_uv);
   float dot = 0.0f;
   for (int k = tid; k < H1; k += 256) {
     float d = 0.0f;
     for (int s = 0; s < n_dsplit; ++s) d += Dslab[((int64_t)s * H2 + n) * H1 + k];
+    d *= dscale;
     dW2[(int64_t)n * H1 + k] = w3n * d;
     dot += w2[(int64_t)n * H1 + k] * d;
   }

@@ -17,10 +17,11 @@ _PKG_ROOT = os.path.dirname(_HERE)
 LIB_PATH = os.environ.get("MI_CRITIC_LIB", os.path.join(_PKG_ROOT, "lib", "libmi_critic_hip.so"))
 
 MI_DV, MI_INFONCE = 0, 1
-MI_PREC_F32, MI_PREC_BF16, MI_PREC_BF16X3, MI_PREC_FP8 = 0, 1, 2, 3
+MI_PREC_F32, MI_PREC_BF16, MI_PREC_BF16X3, MI_PREC_FP8, MI_PREC_F16, MI_PREC_F16X3 = 0, 1, 2, 3, 4, 5
 ESTIMATORS = {"dv": MI_DV, "infonce": MI_INFONCE}
 PRECISIONS = {"f32": MI_PREC_F32, "fp32": MI_PREC_F32, "float32": MI_PREC_F32, "f32_exact": MI_PREC_F32,
-              "bf16": MI_PREC_BF16, "bfloat16": MI_PREC_BF16, "bf16x3": MI_PREC_BF16X3, "fp8": MI_PREC_FP8}
+              "bf16": MI_PREC_BF16, "bfloat16": MI_PREC_BF16, "bf16x3": MI_PREC_BF16X3, "fp8": MI_PREC_FP8,
+              "f16": MI_PREC_F16, "fp16": MI_PREC_F16, "float16": MI_PREC_F16}
 # names that ask for "fp32 results" without insisting on exact fp32 products (see resolve_precision)
 F32_NAMES = ("f32", "fp32", "float32")
 

@@ -342,6 +342,9 @@ def fused_mi_bound(embedding_img: torch.Tensor, embedding_txt: torch.Tensor, stu
         raise ValueError("study_id length must equal the batch size")
     if prec in (_hip.MI_PREC_BF16X3, _hip.MI_PREC_FP8) and not isinstance(critic, _model.BilinearCritic):
         raise ValueError(f'precision="{precision}" is implemented for BilinearCritic only')
+    if prec in (_hip.MI_PREC_F16, _hip.MI_PREC_F16X3) and isinstance(critic, (_model.BilinearCritic, _model.SeparableCritic)):
+        raise ValueError(f'precision="{precision}" is the fp16-operand mode of the make_mlp critic (its generated operand '
+                         'relu(U_i + V_j) is formed by packed fp16 arithmetic); use "bf16" for this critic')
     if isinstance(critic, _model.BilinearCritic):
         loss, stats, scores = BilinearCriticFn.apply(embedding_img, embedding_txt, critic.weight, sid, code, prec,
                                                      bool(return_scores))

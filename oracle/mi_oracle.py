@@ -423,6 +423,74 @@ def concat_step_rounded(x, y, study_id, params, estimator: str, row_block: int =
     return {"scores": s_all, "loss": loss, "dx": du @ w1[:, :dx], "dy": dv @ w1[:, dx:], "dparams": dparams}
 
 
+def round_f16(t: torch.Tensor) -> torch.Tensor:
+    return t.to(torch.float16).to(t.dtype)
+
+
+def f16_pow2_scale(a: float, lo_exp: int) -> float:
+    """2^e with 2^e * a in [2^lo_exp, 2^(lo_exp + 1)) for finite a > 0, else 1 (csrc/mi_concat_bwd.h f16_pow2_scale)."""
+    if not (a > 0.0) or math.isinf(a):
+        return 1.0
+    _, e = math.frexp(a)
+    return 2.0 ** (lo_exp + 1 - e)
+
+
+def concat_step_f16(x, y, study_id, params, estimator: str, row_block: int = 64):
+    """fp64 forward + backward of the factorised concat-MLP critic with the rounding points of the library's fp16 mode
+    (csrc/mi_concat_f16.h, MI_PREC_F16), the backward in closed form:
+
+      scales    s_uv, s_w, s_ww: powers of two from the absmax of U, V, W2, w3 (f16_pow2_scale); s_g = 2^12
+      forward   Uh = fp16(U s_uv), Vh = fp16(V s_uv); h = fp16(clamp(Uh_i + Vh_j, 0, 1)) (packed fp16 add with the clamp
+                modifier = relu); W2h = fp16(W2 s_w);  Z2 = (h W2h^T) / (s_uv s_w) + b2;  scores from Z2 unrounded
+      dU / dV   E[p, k] = sum_n M[p, n] fp16(w3[n] W2[n, k] s_ww) / s_ww; relu' of layer 1 decided on Uh_i + Vh_j > 0
+      dW2 ...   D[n, k] = sum_p M[p, n] fp16(fp16(g_p s_g) h_pk) / (s_uv s_g)
+      everything else (first layer, bound, g, the finishing sums) exact.
+
+    The absmax values are taken from fp32 U, V as the library does (its first layer is an exact-fp32 GEMM)."""
+    w1, b1, w2, b2, w3, b3 = [p.detach() for p in params]
+    x, y = x.detach(), y.detach()
+    b, dx = x.shape
+    w3v = w3.reshape(-1)
+    u = F.linear(x, w1[:, :dx])
+    v = F.linear(y, w1[:, dx:], b1)
+    f32max = lambda t: float(t.float().abs().max())  # noqa: E731
+    s_uv = f16_pow2_scale(float(torch.tensor(f32max(u), dtype=torch.float32) + torch.tensor(f32max(v), dtype=torch.float32)), -2)
+    s_w = f16_pow2_scale(f32max(w2), 13)
+    s_ww = f16_pow2_scale(float(torch.tensor(f32max(w2), dtype=torch.float32) * torch.tensor(f32max(w3v), dtype=torch.float32)), 13)
+    s_g = 4096.0
+    uh, vh = round_f16(u * s_uv), round_f16(v * s_uv)
+    w2h = round_f16(w2 * s_w)
+    w2w = round_f16(w2 * w3v[:, None] * s_ww) / s_ww  # [h2, h1]
+
+    def block(s):
+        pre = uh[s:s + row_block, None, :] + vh[None, :, :]
+        h = round_f16(torch.clamp(pre, 0.0, 1.0))
+        z2 = F.linear(h, w2h) / (s_uv * s_w) + b2
+        return pre, h, z2
+
+    s_all = torch.cat([F.linear(F.relu(block(s)[2]), w3, b3).squeeze(-1) for s in range(0, b, row_block)], 0)
+    loss = bound_from_matrix(s_all, study_id, estimator)
+    g = matrix_grad_scores(s_all, study_id)
+    du = torch.zeros_like(u)
+    dv = torch.zeros_like(v)
+    dmat = torch.zeros_like(w2)
+    mvec = torch.zeros_like(b2)
+    for s in range(0, b, row_block):
+        pre, h, z2 = block(s)
+        gb = g[s:s + row_block, :, None]
+        m = (z2 > 0).to(x.dtype)
+        dh1 = gb * (pre > 0).to(x.dtype) * (m @ w2w)
+        du[s:s + row_block] = dh1.sum(1)
+        dv += dh1.sum(0)
+        hf = round_f16(round_f16(gb * s_g) * h)
+        dmat += torch.einsum("ijn,ijk->nk", m, hf) / (s_uv * s_g)
+        mvec += (gb * m).sum((0, 1))
+    dparams = [torch.cat([du.t() @ x, dv.t() @ y], 1), dv.sum(0), w3v[:, None] * dmat, w3v * mvec,
+               ((w2 * dmat).sum(1) + b2 * mvec).reshape(w3.shape), g.sum().reshape(b3.shape)]
+    return {"scores": s_all, "loss": loss, "dx": du @ w1[:, :dx], "dy": dv @ w1[:, dx:], "dparams": dparams,
+            "scales": (s_uv, s_w, s_ww)}
+
+
 def concat_relu_flip_budget(x, y, params, margin: float, round_fn=None):
     """How far can the choice of relu'(0) move the gradients?  A second-layer pre-activation within the forward's own
     rounding noise of zero comes out on either side in two correct implementations (the 16-bit path rounds H1 to bf16:

@@ -495,6 +495,42 @@ def test_concat_bf16_backward_vs_rounded_oracle(dev, b, dx, dy, h1, h2, dup):
         assert err_e < (1e-5 if name == "db3" else 0.5), (name, err_e)
 
 
+# fp16 mode (MI_PREC_F16, csrc/mi_concat_f16.h): fp16 MFMA operands under power-of-two tensor scales, the generated operand
+# formed by packed fp16 arithmetic.  Parity is defined against orc.concat_step_f16, the fp64 oracle that scales and rounds
+# where the kernels do: scores 3e-4 * max(1, |S|max) (the products are exact in fp32; what is left is the accumulation
+# order and the rare fp16 neighbour an fp32 first layer rounds to where the fp64 one does not), gradients 1e-2 * max|grad|
+# (+ the relu'(0) budget, see test_concat_all_gradients_at_size); against the unrounded oracle the same sanity bound as
+# the bf16 mode.
+@pytest.mark.parametrize("b,dx,dy,h1,h2,dup", CONCAT_CASES)
+def test_concat_f16_vs_rounded_oracle(dev, b, dx, dy, h1, h2, dup):
+    x, y, sid, params = orc.synthetic_case(b, dx, dy, h1=h1, h2=h2, salt=b, dup=dup)
+    loss, scores, grads = _concat_step(dev, x, y, sid, params, (h1, h2), "dv", "f16")
+    p64 = [p.double() for p in params]
+    o = orc.concat_matrix_step(x.double(), y.double(), sid, p64, "dv")
+    orr = orc.concat_step_f16(x.double(), y.double(), sid, p64, "dv")
+    sc = max(float(o["scores"].abs().max()), 1.0)
+    np.testing.assert_allclose(scores.cpu().numpy(), orr["scores"].numpy(), rtol=0, atol=3e-4 * sc)
+    np.testing.assert_allclose(scores.cpu().numpy(), o["scores"].numpy(), rtol=0, atol=4e-3 * sc)  # 8x closer than bf16
+    assert abs(float(loss) - float(orr["loss"])) < 3e-4 * sc
+    margin = 2.0 ** -11 * 2.0 * float(p64[2].abs().max())
+    budget = orc.concat_relu_flip_budget(x.double(), y.double(), p64, margin, round_fn=orc.round_f16)
+    exact = [o["dx"], o["dy"]] + list(o["dparams"])
+    rounded = [orr["dx"], orr["dy"]] + list(orr["dparams"])
+    errs = {}
+    for name, got, ref, rref in zip(GRAD_NAMES, grads, exact, rounded):
+        ref, rref = ref.reshape(got.shape), rref.reshape(got.shape)
+        scale = 1.0 if name == "db3" else float(ref.abs().max())
+        err = (got.double() - rref).abs()
+        slack = budget.get(name)
+        if slack is not None:
+            err = (err - slack.reshape(got.shape)).clamp_min(0.0)
+        errs[name] = float(err.max()) / scale
+        assert float((got.double() - ref).abs().max()) / scale < (1e-5 if name == "db3" else 0.5), name
+    print("fp16 concat errors vs the fp16-rounding oracle:", {k: f"{v:.2e}" for k, v in errs.items()})
+    for name, err in errs.items():
+        assert err < (1e-5 if name == "db3" else 1e-2), (name, err, errs)
+
+
 # ------------------------------------------------------------------------------------------------ row-block sharding
 @pytest.mark.parametrize("critic,precision,b,d,G", [
     ("bilinear", "f32_exact", 192, 64, 3), ("bilinear", "f32", 192, 64, 3), ("bilinear", "bf16", 192, 64, 3), ("concat_mlp", "f32", 192, 64, 3),
