@@ -71,6 +71,12 @@ def parse_args():
     p.add_argument("--critic", default="bilinear", choices=["bilinear", "concat_mlp"])
     p.add_argument("--estimator", default="infonce", choices=["dv", "infonce"])
     p.add_argument("--precision", default="bf16", choices=["bf16", "f32", "f32_exact", "bf16x3", "fp8", "f16"])
+    p.add_argument("--boundary", default="f32", choices=["bf16", "f32"],
+                   help="dtype of the embeddings handed to the step and of the gradients handed back (one GPU, bilinear "
+                        "critic, precision bf16): f32 = the reference's boundary (fp32 embeddings, model.py:540-555; the "
+                        "headline of every round); bf16 = mi_bilinear_step_bf16, what encoders under autocast emit (the kernels "
+                        "round fp32 embeddings to bf16 as their first act: same bits).  The line carries the other one as "
+                        "`other_boundary`")
     p.add_argument("--graph", default="auto", choices=["auto", "on", "off", "full"],
                    help="on: replay the step from a hipGraph (one GPU: GraphedMiStep; N GPUs: the two compute sections "
                         "are graphs, the RCCL collectives stay eager between them).  off: the same C-ABI calls issued one "
@@ -206,7 +212,8 @@ def kernel_flops(name, br, b, d_img, d_txt, h1=1024, h2=512):
 class Stepper:
     """One critic forward + backward through the product API (no autograd anywhere in the timed path)."""
 
-    def __init__(self, kind, args, rank, world, device, group, precision=None, graph=True, batch=None, dim=None):
+    def __init__(self, kind, args, rank, world, device, group, precision=None, graph=True, batch=None, dim=None,
+                 boundary="f32"):
         from mutual_info_img_txt.graphed import GraphedMiStep
         self.kind, self.world, self.device = kind, world, device
         d = dim or args.dim
@@ -235,8 +242,12 @@ class Stepper:
                                                  capture="full" if args.graph == "full" else bool(graph))
             self.eager_obj = self.step_obj if not graph else None
         else:
-            self.step_obj = GraphedMiStep(self.critic, batch, d, d, args.estimator, precision, device, capture=bool(graph))
-            self.step_obj.set_inputs(x, y, sid)
+            self.step_obj = GraphedMiStep(self.critic, batch, d, d, args.estimator, precision, device, capture=bool(graph),
+                                          boundary=boundary)
+            # both boundaries see the same VALUES: the synthetic embeddings rounded to bf16 (exact in fp32)
+            if precision == "bf16" and kind == "bilinear":
+                x, y = x.bfloat16().float(), y.bfloat16().float()
+            self.step_obj.set_inputs(x.to(self.step_obj.x.dtype), y.to(self.step_obj.y.dtype), sid)
             self.eager_obj = self.step_obj
 
     def step(self):
@@ -363,6 +374,8 @@ def profile_kernels(stepper, steps):
 
 # profiling-hook kernel name -> substring of the rocprofv3 kernel name in profiles/*_pmc_traffic.json
 PMC_KERNEL_OF = {
+    "bilinear prep + T = X W (bf16 in)": "bilinear_prep_t_kernel",
+    "bilinear prep + T = X W": "bilinear_prep_t_kernel",
     "bilinear fused S | P Y | P^T T": "bilinear_flash_kernel",
     "bilinear sums -> dT, dY | dX = dT W^T": "flash_tail_kernel",
     "bilinear sums -> loss, dT, dY | dX = dT W^T": "flash_tail_kernel",
@@ -532,8 +545,10 @@ def main():
     want_graph = args.graph in ("on", "auto", "full")
     b, d, br = args.batch, args.dim, args.batch // world
 
-    def run(kind, steps, warmup, precision=None, timed_iters=0, batch=None, dim=None, clock_ms=None, cold_first=False):
-        st = Stepper(kind, args, rank, world, device, group, precision=precision, graph=want_graph, batch=batch, dim=dim)
+    def run(kind, steps, warmup, precision=None, timed_iters=0, batch=None, dim=None, clock_ms=None, cold_first=False,
+            boundary="f32"):
+        st = Stepper(kind, args, rank, world, device, group, precision=precision, graph=want_graph, batch=batch, dim=dim,
+                     boundary=boundary)
         if args.graph == "auto":
             st.choose_launch_mode(world)
         # the contract's W + K steps from a young process first (no clock warm-up): `cold_ms_per_step`
@@ -544,7 +559,11 @@ def main():
         kernels = profile_kernels(st, args.profile_steps)
         return st, elapsed, kernels, timing
 
-    st, elapsed, kernels, timing = run(args.critic, args.steps, args.warmup, timed_iters=args.timed_iters, cold_first=True)
+    # the bf16 boundary exists for the bilinear critic in bf16 precision on one GPU (sharded runs gather fp32 rows)
+    boundary = args.boundary if (args.critic == "bilinear" and args.precision == "bf16" and world == 1 and
+                                 not os.environ.get("MI_BENCH_FORCE_DIST")) else "f32"
+    st, elapsed, kernels, timing = run(args.critic, args.steps, args.warmup, timed_iters=args.timed_iters, cold_first=True,
+                                       boundary=boundary)
     ms = elapsed / args.steps * 1e3
     cold_ms = st.cold_elapsed / args.steps * 1e3
     flops = algorithmic_flops(args.critic, b, d, d)
@@ -570,6 +589,8 @@ def main():
                                f"{args.critic} critic fwd+bwd, B_global={b}, d={d}",
                    "global_batch": b, "embed_dim": d, "critic": args.critic, "estimator": args.estimator,
                    "parallelism": f"row-block sharding x{world}, RCCL all-gather of text embeddings" if world > 1 else "single GPU",
+                   "boundary": ("bf16 embeddings in, bf16 dX / dY out (mi_bilinear_step_bf16); W, dW, loss fp32" if boundary == "bf16"
+                                else "fp32 embeddings in, fp32 gradients out"),
                    "hip_graph": not st.use_eager, "graph_mode": graph_mode},
         "loss": st.loss(),
         "timing": dict(timing or {}, clock_warmup={"budget_ms": args.clock_warmup_ms, "untimed_steps": st.clock_warmup_steps,
@@ -584,6 +605,26 @@ def main():
     }
     del st
     torch.cuda.empty_cache()
+    if args.critic == "bilinear" and args.precision == "bf16" and world == 1 and not os.environ.get("MI_BENCH_FORCE_DIST"):
+        # the same step on the same values through the other boundary (measured round 4: the bf16 boundary moves 25 MB less
+        # per step and is NOT faster -- the conversion launch is bound by its chain of dependent k-steps, not by bytes)
+        other = "f32" if boundary == "bf16" else "bf16"
+        try:
+            stf, elf, kf, _ = run(args.critic, args.steps, args.warmup, cold_first=True, boundary=other)
+            msf = elf / args.steps * 1e3
+            out["other_boundary"] = {
+                "boundary": "bf16 embeddings in, bf16 dX / dY out (mi_bilinear_step_bf16)" if other == "bf16"
+                            else "fp32 embeddings in, fp32 gradients out (mi_bilinear_step)",
+                "ms_per_step": round(msf, 5), "cold_ms_per_step": round(stf.cold_elapsed / args.steps * 1e3, 5),
+                "value": round(b / (msf * 1e-3), 1), "unit": "pairs/s", "loss": stf.loss(),
+                "step_frac_of_peak": round(flops / (msf * 1e-3) / 1e12 / (PEAK_TFLOPS[args.precision] * world), 5),
+                "kernels_us": {k: round(v["ms_avg"] * 1e3, 2) for k, v in sorted(kf.items(), key=lambda kv: -kv[1]["ms_total"])},
+                "note": "bit-identical loss, statistics and dW on the same bf16-representable values "
+                        "(tests/test_graphed_step.py::test_bf16_boundary_equals_fp32_boundary)"}
+            del stf
+        except Exception as e:
+            out["other_boundary"] = {"error": f"{type(e).__name__}: {e}"}
+        torch.cuda.empty_cache()
     if not args.no_parity_mode and args.precision not in ("f32", "f32_exact"):
         # the same step in the mode whose results match the fp32 reference
         out["parity_mode"] = {}

@@ -204,6 +204,17 @@ int mi_bilinear_step(const float* x, const float* y, const float* w, const int64
                      mi_stats* stats, float* partials_out, float* grad_x, float* grad_y, float* grad_w, void* workspace,
                      size_t workspace_bytes, void* stream);
 
+/* The step at a bf16 boundary (ABI 4): x_bf16 [b][d_img], y_bf16 [b][d_txt] hold bfloat16 -- what the encoders emit under
+ * autocast (model.py:540-555 run in bf16) --; grad_x / grad_y are bfloat16 buffers when grads_bf16 != 0, float32 buffers
+ * otherwise; w, grad_w, the loss and the statistics are float32.  The kernels' first act on fp32 embeddings is to round
+ * them to bf16, so this entry point computes the same bits as mi_bilinear_step(precision = MI_PREC_BF16) on the same
+ * bf16-representable values; what it saves is the 25 MB of conversion traffic per step at B = 4096, d = 512.  Shapes:
+ * mi_bilinear_path(b, b, d_img, d_txt, MI_PREC_BF16) == MI_PATH_FUSED_TAIL, 16-byte aligned embeddings; else MI_ESHAPE. */
+int mi_bilinear_step_bf16(const void* x_bf16, const void* y_bf16, const float* w, const int64_t* sid, int64_t b,
+                          int64_t d_img, int64_t d_txt, int estimator, const float* grad_out, float* loss_out,
+                          mi_stats* stats, float* partials_out, void* grad_x, void* grad_y, int grads_bf16,
+                          float* grad_w, void* workspace, size_t workspace_bytes, void* stream);
+
 /* Which kernels a shape takes: one of MI_PATH_* (or a negative MI_E* code).  Host-side arithmetic on the plan only; the
  * Python binding uses it to warn once per shape when a 16-bit call leaves the fused kernels. */
 int mi_bilinear_path(int64_t b_rows, int64_t b, int64_t d_img, int64_t d_txt, int precision);

@@ -186,6 +186,21 @@ static int fast_prep_and_t(const float* x, const float* y, const float* w, const
   return launch_gemm_bf16(one_problem(p.xb, x3 * dx, p.wtb, x3 * dx, br, dy, x3 * dx), 1, e, st, "bilinear T = X W");
 }
 
+// The bf16 boundary: x [br][dx] and y [b][dy] arrive as bf16 (encoders under autocast).  Same launch as above minus the
+// conversions: T tiles from the bf16 rows as they lie, X^T / Y fragment-major copies, W copies, the equal-id flags; the
+// row-major bf16 copy of Y IS the input.
+static int fast_prep_and_t_bf16(const bf16_t* x, const bf16_t* y, const float* w, const int64_t* sid_rows,
+                                const int64_t* sid_cols, int64_t br, int64_t b, int64_t row_offset, int64_t dx, int64_t dy,
+                                const BilinearPlan& p, hipStream_t st) {
+  CvtJobs side{};
+  side.j[0] = CvtJob{reinterpret_cast<const float*>(x), br, dx, nullptr, nullptr, 0, 0, nullptr, 0, 0, p.xtfb, 1};
+  side.j[1] = CvtJob{reinterpret_cast<const float*>(y), b, dy, nullptr, nullptr, 0, 0, p.yfb, 0, 0, nullptr, 1};
+  side.j[2] = CvtJob{w, dx, dy, p.wb, nullptr, 0, 0, p.wfb};
+  side.dup = DupFlagJob{sid_rows, sid_cols, (int)(br / 32), (int)(b / 32), p.fl_dup[0], p.fl_dup[1], row_offset};
+  return launch_prep_t(reinterpret_cast<const float*>(x), w, br, dy, dx, p.tb, p.tfb, side, st,
+                       "bilinear prep + T = X W (bf16 in)", true);
+}
+
 static int bilinear_bwd_small(int64_t br, int64_t dx, int64_t dy, float* grad_x, float* grad_w, const BilinearPlan& p,
                               hipStream_t st);
 
@@ -214,6 +229,7 @@ struct TailMerge {
   float* partials_out;
   const float* records = nullptr;  // sharded: the raw records gathered from every rank (rank order), else the workspace's
   int64_t n_records = 0, n_pos = 0;
+  int grads_bf16 = 0;              // grad_x / grad_y point to bf16 buffers (the bf16 boundary)
 };
 static int bilinear_tail(int64_t br, int64_t b, int64_t row_offset, int64_t dx, int64_t dy, const mi_stats* stats,
                          const float* grad_out, float* grad_x, float* grad_y, float* grad_w, const BilinearPlan& p,
@@ -221,8 +237,9 @@ static int bilinear_tail(int64_t br, int64_t b, int64_t row_offset, int64_t dx, 
   FlashTailArgs ta{};
   ta.j[0] = FlashReduceJob{p.fl_slab[0], p.fl_rec[0], p.fl.n_split[0], p.fl.n_rb[0], br, p.yb, b, row_offset,
                            nullptr, nullptr, nullptr};
+  const bool gbf = merge && merge->grads_bf16;
   ta.j[1] = FlashReduceJob{p.fl_slab[1], p.fl_rec[1], p.fl.n_split[1], p.fl.n_rb[1], b, p.tb, br, -row_offset,
-                           grad_y, nullptr, nullptr};
+                           gbf ? nullptr : grad_y, gbf ? reinterpret_cast<bf16_t*>(grad_y) : nullptr, nullptr};
   ta.stats = stats;
   ta.grad_out = grad_out;
   if (merge) {
@@ -242,6 +259,10 @@ static int bilinear_tail(int64_t br, int64_t b, int64_t row_offset, int64_t dx, 
 #else
   ta.grad_x = grad_x;
 #endif
+  if (gbf) {
+    ta.grad_x_bf = reinterpret_cast<bf16_t*>(grad_x);
+    ta.grad_x = nullptr;
+  }
   ta.dtt_frag = p.dttfb;
   int rc = launch_flash_tail(ta, dy, p.fl.slab_f16, merge != nullptr, st,
                              merge ? "bilinear sums -> loss, dT, dY | dX = dT W^T" : "bilinear sums -> dT, dY | dX = dT W^T");
@@ -791,6 +812,46 @@ int mi_bilinear_step(const float* x, const float* y, const float* w, const int64
   if (rc) return rc;
   return mi_bilinear_bwd(x, y, w, sid, sid, b, b, 0, d_img, d_txt, precision, stats, grad_out, grad_x, grad_y, grad_w,
                          workspace, workspace_bytes, 1, stream);
+}
+
+/* The same step at a bf16 boundary: x [b][d_img] and y [b][d_txt] are bf16 (what encoders under the autocast policy of
+ * encoders.py emit), the gradients for them are written in bf16 when grads_bf16 != 0 (fp32 buffers otherwise); w, grad_w,
+ * loss and statistics stay fp32.  The kernels round x and y to bf16 as their first act anyway: with bf16-representable
+ * inputs the results are bit-identical to mi_bilinear_step(precision = MI_PREC_BF16), minus 25 MB of conversion traffic
+ * per step.  Only where the fused kernels and the two-launch tail take the shape (mi_bilinear_path == MI_PATH_FUSED_TAIL);
+ * MI_ESHAPE otherwise (convert and call mi_bilinear_step). */
+int mi_bilinear_step_bf16(const void* x_bf16, const void* y_bf16, const float* w, const int64_t* sid, int64_t b,
+                          int64_t d_img, int64_t d_txt, int estimator, const float* grad_out, float* loss_out,
+                          mi_stats* stats, float* partials_out, void* grad_x, void* grad_y, int grads_bf16, float* grad_w,
+                          void* workspace, size_t workspace_bytes, void* stream) {
+  MI_CHECK_ARG(x_bf16 && y_bf16 && w && sid && stats && grad_x && grad_y && grad_w && workspace,
+               "mi_bilinear_step_bf16: null pointer");
+  int rc = check_common("mi_bilinear_step_bf16", b, b, 0, d_img, d_txt, MI_PREC_BF16);
+  if (rc) return rc;
+  MI_CHECK_ARG(estimator == MI_DV || estimator == MI_INFONCE, "mi_bilinear_step_bf16: unknown estimator %d", estimator);
+  Workspace ws(workspace, workspace_bytes);
+  BilinearPlan p = plan_bilinear(ws, b, b, d_img, d_txt, MI_PREC_BF16);
+  if (!ws.ok()) {
+    set_error("mi_bilinear_step_bf16: workspace too small (%zu < %zu)", workspace_bytes, ws.off);
+    return MI_EWORKSPACE;
+  }
+  if (!(fast_ok(b, b, d_img, d_txt, MI_PREC_BF16, true) && p.fl.ok && p.tail) || (uintptr_t)x_bf16 % 16 != 0 ||
+      (uintptr_t)y_bf16 % 16 != 0) {
+    set_error("mi_bilinear_step_bf16: shape outside the fused kernels (mi_bilinear_path != MI_PATH_FUSED_TAIL) or "
+              "embeddings not 16-byte aligned: convert to fp32 and call mi_bilinear_step");
+    return MI_ESHAPE;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  const bf16_t* xb = reinterpret_cast<const bf16_t*>(x_bf16);
+  p.yb = const_cast<bf16_t*>(reinterpret_cast<const bf16_t*>(y_bf16));  // the streamed operand of problem 0: the input itself
+  rc = fast_prep_and_t_bf16(xb, p.yb, w, sid, sid, b, b, 0, d_img, d_txt, p, st);
+  if (rc) return rc == MI_EINVAL ? MI_ESHAPE : rc;
+  rc = flash_stage(sid, sid, b, b, 0, d_txt, true, p, st);
+  if (rc) return rc;
+  TailMerge m{estimator, loss_out, stats, partials_out};
+  m.grads_bf16 = grads_bf16 ? 1 : 0;
+  return bilinear_tail(b, b, 0, d_img, d_txt, stats, grad_out, reinterpret_cast<float*>(grad_x),
+                       reinterpret_cast<float*>(grad_y), grad_w, p, &m, st);
 }
 
 /* Which kernels a bilinear-critic shape takes (host-side arithmetic only, nothing is launched): MI_PATH_*.  The Python

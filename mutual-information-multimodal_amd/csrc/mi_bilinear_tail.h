@@ -37,6 +37,7 @@ struct FlashTailArgs {
   const bf16_t* w_frag;      // W [dx][D] fragment-major: block (a / 32, c / 16)
   int64_t dx;
   float* grad_x;             // [m0][dx]
+  bf16_t* grad_x_bf;         // [m0][dx] bf16 instead (the bf16 boundary: mi_bilinear_step_bf16) or null
   bf16_t* dtt_frag;          // dT^T [D][m0] fragment-major: block (c / 32, i / 16); operand of bilinear_dw_kernel
   int n_blocks0;             // 32-row blocks of job 0 (they come first in the grid: the longer ones)
 };
@@ -45,7 +46,9 @@ constexpr int kTailPad = 4;  // floats of padding per LDS row: 16-byte row reads
 constexpr int kTailThreads = 512;  // eight waves: the grid is one workgroup per CU, so the loads a CU keeps in flight are
                                    // this workgroup's; every slab load of the block is issued before the first use
 
-template <int D, bool F16, bool MERGE>
+// GBF: the gradients for the embeddings go out as bf16 (the bf16 boundary) -- a compile-time variant: as a run-time branch the
+// extra store paths pushed the fp32 kernel from 246 registers to 256 + 172 bytes of scratch (17 -> 26 us).
+template <int D, bool F16, bool MERGE, bool GBF = false>
 __global__ __launch_bounds__(kTailThreads, 2) void flash_tail_kernel(FlashTailArgs args) {
   kernarg_prefetch<(int)sizeof(FlashTailArgs)>();
   extern __shared__ __attribute__((aligned(16))) char smem_tail[];
@@ -268,13 +271,19 @@ __global__ __launch_bounds__(kTailThreads, 2) void flash_tail_kernel(FlashTailAr
           for (int e = 0; e < 8; ++e) tile[row][c + e] = v[e];
         }
       }
-      if (J.out_f32) {
+      if constexpr (GBF) {  // the bf16 boundary: the gradient in the dtype of the embeddings (one rounding of the fp32 sum)
+        if (J.out_bf) {
+          const bf16x8 o = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3],
+                            (bf16_t)v[4], (bf16_t)v[5], (bf16_t)v[6], (bf16_t)v[7]};
+          *reinterpret_cast<bf16x8*>(J.out_bf + i * D + c) = o;
+        }
+      } else if (J.out_f32) {
         *reinterpret_cast<f32x4*>(J.out_f32 + i * D + c) = f32x4{v[0], v[1], v[2], v[3]};
         *reinterpret_cast<f32x4*>(J.out_f32 + i * D + c + 4) = f32x4{v[4], v[5], v[6], v[7]};
       }
     }
   }
-  if (job != 0 || args.grad_x == nullptr) return;
+  if (job != 0 || (GBF ? args.grad_x_bf == nullptr : args.grad_x == nullptr)) return;
   __syncthreads();
 
   // ---- dX[i0 .. +32][a] = sum_c dT[i][c] W[a][c]: A = the dT tile (rows on the lane; bf16 from LDS), B = W fragments
@@ -351,19 +360,22 @@ __global__ __launch_bounds__(kTailThreads, 2) void flash_tail_kernel(FlashTailAr
 #pragma unroll
       for (int g = 0; g < 4; ++g)
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
-          args.grad_x[(i0 + 8 * g + 4 * h + e) * args.dx + (at0 + t) * 32 + r] = acc[t][4 * g + e];
+        for (int e = 0; e < 4; ++e) {
+          const int64_t o = (i0 + 8 * g + 4 * h + e) * args.dx + (at0 + t) * 32 + r;
+          if constexpr (GBF) args.grad_x_bf[o] = (bf16_t)acc[t][4 * g + e];
+          else args.grad_x[o] = acc[t][4 * g + e];
+        }
     }
   }
 }
 
-template <int D, bool F16, bool MERGE>
+template <int D, bool F16, bool MERGE, bool GBF = false>
 static inline int launch_flash_tail_t(const FlashTailArgs& a, unsigned grid, hipStream_t st, const char* what) {
   const size_t smem = (size_t)32 * (D + kTailPad) * sizeof(float) + 128;
-  MI_SET_DYN_SMEM((flash_tail_kernel<D, F16, MERGE>), smem, "hipFuncSetAttribute(flash_tail_kernel)");
+  MI_SET_DYN_SMEM((flash_tail_kernel<D, F16, MERGE, GBF>), smem, "hipFuncSetAttribute(flash_tail_kernel)");
   {
     ProfScope prof_(what, st);
-    hipLaunchKernelGGL((flash_tail_kernel<D, F16, MERGE>), dim3(grid), dim3(kTailThreads), smem, st, a);
+    hipLaunchKernelGGL((flash_tail_kernel<D, F16, MERGE, GBF>), dim3(grid), dim3(kTailThreads), smem, st, a);
   }
   MI_LAUNCH_CHECK(what);
   return MI_OK;
@@ -375,6 +387,13 @@ static inline int launch_flash_tail(FlashTailArgs a, int64_t d, bool slab_f16, b
   const unsigned grid = (unsigned)(a.n_blocks0 + a.j[1].m / 32);
 #define MI_TAIL_CASE(DD)                                                                          \
   if (d == DD) {                                                                                  \
+    if (a.grad_x_bf) {  /* the bf16 boundary: fp16 slabs, merged statistics (mi_bilinear_step_bf16) */ \
+      if (!(slab_f16 && merge)) {                                                                 \
+        set_error("launch_flash_tail: bf16 gradients need fp16 slabs and the merged form");       \
+        return MI_EINVAL;                                                                         \
+      }                                                                                           \
+      return launch_flash_tail_t<DD, true, true, true>(a, grid, st, what);                        \
+    }                                                                                             \
     if (slab_f16) return merge ? launch_flash_tail_t<DD, true, true>(a, grid, st, what)           \
                                : launch_flash_tail_t<DD, true, false>(a, grid, st, what);         \
     return merge ? launch_flash_tail_t<DD, false, true>(a, grid, st, what)                        \

@@ -642,23 +642,26 @@ __global__ __launch_bounds__(256, 2) void concat_bwd_duv3_kernel(
       for (int ct = 0; ct < NT; ++ct)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[m][ct][r] = 0.0f;
-    float vn[4][NT];
+    // the epilogue's V values: issued before the step's MFMAs (8 registers; issued under the last block of MFMAs their
+    // latency was still exposed: the fp16 form, whose 2-byte loads return later, ran 5 % behind the bf16 form)
+    UvT vraw[4][NT];
+#pragma unroll
+    for (int jq = 0; jq < 4; ++jq) {
+      int64_t gj = j + jq;
+      if (gj >= b) gj = b - 1;
+#pragma unroll
+      for (int ct = 0; ct < NT; ++ct) {
+        int k = kc0 + 32 * ct + c;
+        if (k >= H1) k = H1 - 1;
+        vraw[jq][ct] = V[gj * H1 + k];
+      }
+    }
+    // (A hand-pipelined form of this loop -- the four fragments of step s + 2 fetched through rotating register sets before
+    // the MFMAs of step s -- made hipcc extract table indices far ahead and spill: 224 - 400 bytes of scratch reloaded
+    // between the MFMAs, 22 ms against 14; profiles/README.md.)
 #pragma unroll
     for (int pw = 0; pw < 4; ++pw) {
       if (pw < hw) {
-        if (pw == hw - 1) {  // the epilogue's -V values: issued under the last block of MFMAs
-#pragma unroll
-          for (int jq = 0; jq < 4; ++jq) {
-            int64_t gj = j + jq;
-            if (gj >= b) gj = b - 1;
-#pragma unroll
-            for (int ct = 0; ct < NT; ++ct) {
-              int k = kc0 + 32 * ct + c;
-              if (k >= H1) k = H1 - 1;
-              vn[jq][ct] = -(float)V[gj * H1 + k];
-            }
-          }
-        }
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
           Vec8 af[2];
@@ -680,11 +683,14 @@ __global__ __launch_bounds__(256, 2) void concat_bwd_duv3_kernel(
     // ---- epilogue: relu' of layer 1, g, row / column sums -------------------------------------------------------------
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    float dvp[4][NT];
+    float dvp[4][NT], vn[4][NT];
 #pragma unroll
     for (int jq = 0; jq < 4; ++jq)
 #pragma unroll
-      for (int ct = 0; ct < NT; ++ct) dvp[jq][ct] = 0.0f;
+      for (int ct = 0; ct < NT; ++ct) {
+        dvp[jq][ct] = 0.0f;
+        vn[jq][ct] = -(float)vraw[jq][ct];
+      }
 #pragma unroll
     for (int m = 0; m < 2; ++m)
 #pragma unroll

@@ -1451,6 +1451,7 @@ struct CvtJob {
   int split_rm;         // bf16x3 mode (split3_offsets): out_rm is [R][3 C] holding hi and lo parts; 0: plain bf16
   int split_t;          // same for out_t, [C][3 R]
   bf16_t* out_t_frag;   // fragment-major copy of the TRANSPOSE [C][R] (C % 32 == 0, R % 16 == 0) or null
+  int in_bf16;          // `in` points to bf16 data (the bf16 boundary, mi_bilinear_step_bf16): copies instead of conversions
 };
 // equal-id flags of the fused bilinear kernel, computed by spare workgroups of the conversion launch (blockIdx.z == 3)
 struct DupFlagJob {
@@ -1514,7 +1515,14 @@ __device__ __forceinline__ void cvt_tile_block(const CvtJob& J, int bx, int by, 
   for (int q = 0; q < 4; ++q) {  // all four loads in flight before the first use
     const int64_t r = r0 + ty + 16 * q, c = c0 + 4 * tx;
     vq[q] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-    if (r < J.R && c < J.C) vq[q] = *reinterpret_cast<const f32x4*>(J.in + r * J.C + c);
+    if (r < J.R && c < J.C) {
+      if (J.in_bf16) {
+        const bf16x4 b4 = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const bf16_t*>(J.in) + r * J.C + c);
+        vq[q] = f32x4{(float)b4[0], (float)b4[1], (float)b4[2], (float)b4[3]};
+      } else {
+        vq[q] = *reinterpret_cast<const f32x4*>(J.in + r * J.C + c);
+      }
+    }
   }
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
@@ -1612,10 +1620,15 @@ static inline int launch_cvt_transpose3(const CvtJobs& jobs, hipStream_t st, con
     const CvtJob& J = jobs.j[q];
     if (J.R > rmax) rmax = J.R;
     if (J.C > cmax) cmax = J.C;
-    vec = vec && J.R % 4 == 0 && J.C % 4 == 0 && (uintptr_t)J.in % 16 == 0 && (uintptr_t)J.out_rm % 8 == 0 &&
+    vec = vec && J.R % 4 == 0 && J.C % 4 == 0 && (uintptr_t)J.in % (J.in_bf16 ? 8 : 16) == 0 && (uintptr_t)J.out_rm % 8 == 0 &&
           (uintptr_t)J.out_t % 8 == 0 && J.slab_stride % 4 == 0 && (!J.out_frag || (J.R % 32 == 0 && J.C % 16 == 0)) &&
           (!J.out_t_frag || (J.C % 32 == 0 && J.R % 16 == 0));
   }
+  for (int q = 0; q < 4; ++q)
+    if (!vec && jobs.j[q].R > 0 && jobs.j[q].in_bf16) {
+      set_error("%s: bf16 inputs need the vectorised conversion kernel (aligned, multiples of 4)", what);
+      return MI_ESHAPE;
+    }
   if (!vec && (jobs.dup.na > 0 || jobs.j[0].out_frag || jobs.j[1].out_frag || jobs.j[2].out_frag || jobs.j[3].out_frag ||
                jobs.j[0].out_t_frag || jobs.j[1].out_t_frag || jobs.j[2].out_t_frag || jobs.j[3].out_t_frag)) {
     set_error("%s: fragment-major outputs / id flags need the vectorised conversion kernel (aligned, multiples of 4)", what);
@@ -1653,10 +1666,14 @@ struct PrepTArgs {
   int job_begin[6];  // conversion blocks (counted from n_t): first block of job q; [4] = flags, [5] = end
   int job_nx[4];     // 64-column tiles per tile row of job q
   CvtJobs jobs;
+  int x_bf16;        // x points to bf16 data [m][k] (the bf16 boundary): the tile goes to LDS as it lies
 };
 constexpr int kPrepTLdB = 160;  // W image row pitch in bf16 elements (128 columns + 32 of padding = 320 bytes)
 constexpr size_t kPrepTSmem = (2 * kTile * kG2LD + 2 * kG2KT * kPrepTLdB) * sizeof(bf16_t);  // 77,824 bytes
 
+// XB16: x arrives as bf16 (a compile-time variant: as a run-time branch the second staging path cost the fp32 kernel 10
+// registers and 48 bytes of scratch)
+template <bool XB16>
 static __global__ __launch_bounds__(256, 2) void bilinear_prep_t_kernel(PrepTArgs a) {
   kernarg_prefetch<(int)sizeof(PrepTArgs)>();
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -1709,24 +1726,48 @@ static __global__ __launch_bounds__(256, 2) void bilinear_prep_t_kernel(PrepTArg
 
   f32x4 rx[8], rw[8];
   const float* xp[8];
+  if constexpr (!XB16) {
 #pragma unroll
-  for (int q = 0; q < 8; ++q) {
-    int64_t row = m0 + xr + 16 * q;
-    if (row >= a.m) row = a.m - 1;  // clamped rows only feed outputs the epilogue drops
-    xp[q] = a.x + row * a.k + 4 * xc;
+    for (int q = 0; q < 8; ++q) {
+      int64_t row = m0 + xr + 16 * q;
+      if (row >= a.m) row = a.m - 1;  // clamped rows only feed outputs the epilogue drops
+      xp[q] = a.x + row * a.k + 4 * xc;
+    }
   }
   const float* wp = a.w + (int64_t)wk * a.n + n0 + 4 * wc;
-  auto load_tile = [&](int64_t k0) {
+  // bf16 x: a 128 x 64 tile is 1024 chunks of 16 bytes, four per thread: rows (tid >> 3) + 32 q, chunk tid & 7; they
+  // travel in rx[0..3] as raw bits
+  const bf16_t* xbp[4];
+  const int br_ = tid >> 3, bc_ = tid & 7;
+  if constexpr (XB16) {
 #pragma unroll
-    for (int q = 0; q < 8; ++q) rx[q] = *reinterpret_cast<const f32x4*>(xp[q] + k0);
+    for (int q = 0; q < 4; ++q) {
+      int64_t row = m0 + br_ + 32 * q;
+      if (row >= a.m) row = a.m - 1;
+      xbp[q] = reinterpret_cast<const bf16_t*>(a.x) + row * a.k + 8 * bc_;
+    }
+  }
+  auto load_tile = [&](int64_t k0) {
+    if constexpr (XB16) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) rx[q] = *reinterpret_cast<const f32x4*>(xbp[q] + k0);
+    } else {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) rx[q] = *reinterpret_cast<const f32x4*>(xp[q] + k0);
+    }
 #pragma unroll
     for (int q = 0; q < 8; ++q) rw[q] = *reinterpret_cast<const f32x4*>(wp + (k0 + 8 * q) * a.n);
   };
   auto store_tile = [&](int buf) {
+    if constexpr (XB16) {
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const bf16x4 o = {(bf16_t)rx[q][0], (bf16_t)rx[q][1], (bf16_t)rx[q][2], (bf16_t)rx[q][3]};
-      *reinterpret_cast<bf16x4*>(&As[(buf * kTile + xr + 16 * q) * kG2LD + 4 * xc]) = o;
+      for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4*>(&As[(buf * kTile + br_ + 32 * q) * kG2LD + 8 * bc_]) = rx[q];
+    } else {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const bf16x4 o = {(bf16_t)rx[q][0], (bf16_t)rx[q][1], (bf16_t)rx[q][2], (bf16_t)rx[q][3]};
+        *reinterpret_cast<bf16x4*>(&As[(buf * kTile + xr + 16 * q) * kG2LD + 4 * xc]) = o;
+      }
     }
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
@@ -1780,19 +1821,20 @@ static __global__ __launch_bounds__(256, 2) void bilinear_prep_t_kernel(PrepTArg
 // conversions: up to four CvtJob (64 x 64 tiles each) + the flag job; returns MI_EINVAL for shapes the fused kernel does
 // not take (the caller then runs the conversion launch and the plain GEMM)
 static inline int launch_prep_t(const float* x, const float* w, int64_t m, int64_t n, int64_t k, bf16_t* tb, bf16_t* tfb,
-                                const CvtJobs& jobs, hipStream_t st, const char* what) {
+                                const CvtJobs& jobs, hipStream_t st, const char* what, bool x_bf16 = false) {
   static const bool off = getenv("MI_NO_PREP_T") != nullptr;  // A/B switch: separate conversion and GEMM launches
   if (off || k % 64 != 0 || n % kTile != 0 || m < 1 || (uintptr_t)x % 16 != 0 || (uintptr_t)w % 16 != 0 ||
       (uintptr_t)tb % 16 != 0 || (tfb && (m % 32 != 0 || (uintptr_t)tfb % 16 != 0)))
     return MI_EINVAL;
   PrepTArgs a{};
   a.x = x; a.w = w; a.m = m; a.n = n; a.k = k; a.tb = tb; a.tfb = tfb;
+  a.x_bf16 = x_bf16 ? 1 : 0;
   a.n_t = (int)(8 * (n / kTile) * (((m + kTile - 1) / kTile + 7) / 8));  // padded for the XCD mapping
   a.jobs = jobs;
   int total = 0;
   for (int q = 0; q < 4; ++q) {
     const CvtJob& J = jobs.j[q];
-    if (J.R > 0 && (J.R % 4 != 0 || J.C % 4 != 0 || (uintptr_t)J.in % 16 != 0 || (uintptr_t)J.out_rm % 8 != 0 ||
+    if (J.R > 0 && (J.R % 4 != 0 || J.C % 4 != 0 || (uintptr_t)J.in % (J.in_bf16 ? 8 : 16) != 0 || (uintptr_t)J.out_rm % 8 != 0 ||
                     (uintptr_t)J.out_t % 8 != 0 || J.n_slab > 1 || (J.out_frag && (J.R % 32 != 0 || J.C % 16 != 0)) ||
                     (J.out_t_frag && (J.C % 32 != 0 || J.R % 16 != 0))))
       return MI_EINVAL;
@@ -1803,13 +1845,17 @@ static inline int launch_prep_t(const float* x, const float* w, int64_t m, int64
   a.job_begin[4] = total;
   if (jobs.dup.na > 0) total += jobs.dup.na * ((jobs.dup.nb + 63) / 64);
   a.job_begin[5] = total;
-  MI_SET_DYN_SMEM(bilinear_prep_t_kernel, kPrepTSmem, "hipFuncSetAttribute(bilinear_prep_t_kernel)");
 #ifdef MI_STAMPS
   stamp_select(what, st);
 #endif
-  {
+  if (x_bf16) {
+    MI_SET_DYN_SMEM(bilinear_prep_t_kernel<true>, kPrepTSmem, "hipFuncSetAttribute(bilinear_prep_t_kernel)");
     ProfScope prof_(what, st);
-    hipLaunchKernelGGL(bilinear_prep_t_kernel, dim3((unsigned)(a.n_t + total)), dim3(256), kPrepTSmem, st, a);
+    hipLaunchKernelGGL(bilinear_prep_t_kernel<true>, dim3((unsigned)(a.n_t + total)), dim3(256), kPrepTSmem, st, a);
+  } else {
+    MI_SET_DYN_SMEM(bilinear_prep_t_kernel<false>, kPrepTSmem, "hipFuncSetAttribute(bilinear_prep_t_kernel)");
+    ProfScope prof_(what, st);
+    hipLaunchKernelGGL(bilinear_prep_t_kernel<false>, dim3((unsigned)(a.n_t + total)), dim3(256), kPrepTSmem, st, a);
   }
   MI_LAUNCH_CHECK(what);
   return MI_OK;

@@ -67,6 +67,7 @@ SIGNATURES = {
     "mi_bilinear_prep_local": (c_int, [_P, _P, _I64, _I64, _I64, _I64, _I, _P, _SZ, _P]),
     "mi_bilinear_fp8_stage": (c_int, [_P, _P, _P, _I64, _I64, _I64, _I64, _I, _P, _P, _SZ, _P]),
     "mi_bilinear_step": (c_int, [_P, _P, _P, _P, _I64, _I64, _I64, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _SZ, _P]),
+    "mi_bilinear_step_bf16": (c_int, [_P, _P, _P, _P, _I64, _I64, _I64, _I, _P, _P, _P, _P, _P, _P, _I, _P, _P, _SZ, _P]),
     "mi_bilinear_path": (c_int, [_I64, _I64, _I64, _I64, _I]),
     "mi_separable_path": (c_int, [_I64, _I64, _I64, _I64, _I64, _I]),
     "mi_separable_workspace_bytes": (_SZ, [_I64, _I64, _I64, _I64, _I64, _I]),

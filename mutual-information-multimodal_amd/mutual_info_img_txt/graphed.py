@@ -29,7 +29,11 @@ from .mi_critics import _concat_params, _estimator_code, _precision_code
 
 class GraphedMiStep:
     def __init__(self, critic, batch_size: int, d_img: int, d_txt: int, estimator: str = "dv", precision: str = "f32",
-                 device=None, capture: bool = True):
+                 device=None, capture: bool = True, boundary: str = "f32"):
+        """``boundary="bf16"`` (bilinear critic in "bf16" precision on the fused kernels only): the step takes bfloat16
+        embeddings -- what the encoders emit under autocast -- and returns their gradients in bfloat16
+        (``mi_bilinear_step_bf16``: the same bits as the fp32 boundary fed the same values, without the 25 MB of
+        conversion traffic per step at B = 4096, d = 512).  The critic's parameters and their gradients stay float32."""
         from . import model as _model
         self.device = torch.device(device if device is not None else "cuda")
         if self.device.type != "cuda":
@@ -59,9 +63,18 @@ class GraphedMiStep:
         for p in self.params:
             if p.device != dev or p.dtype != torch.float32 or not p.is_contiguous():
                 raise ValueError("critic parameters must be contiguous float32 tensors on the step's device")
+        if boundary not in ("f32", "bf16"):
+            raise ValueError('boundary must be "f32" or "bf16"')
+        self.boundary = boundary
+        if boundary == "bf16":
+            if self.kind != "bilinear" or not self.params or self.prec != _hip.MI_PREC_BF16 or \
+                    self.lib.mi_bilinear_path(self.b, self.b, self.dx, self.dy, self.prec) != _hip.MI_PATH_FUSED_TAIL:
+                raise ValueError('boundary="bf16" needs a BilinearCritic in precision "bf16" on a shape of the fused '
+                                 'kernels (batch % 128 == 0, d_txt in {128, 256, 512}, d_img % 32 == 0)')
+        io_dtype = torch.bfloat16 if boundary == "bf16" else torch.float32
         # static inputs
-        self.x = torch.zeros(self.b, self.dx, dtype=torch.float32, device=dev)
-        self.y = torch.zeros(self.b, self.dy, dtype=torch.float32, device=dev)
+        self.x = torch.zeros(self.b, self.dx, dtype=io_dtype, device=dev)
+        self.y = torch.zeros(self.b, self.dy, dtype=io_dtype, device=dev)
         self.sid = torch.arange(self.b, dtype=torch.int64, device=dev)
         self.grad_out = torch.ones(1, dtype=torch.float32, device=dev)
         # static outputs
@@ -104,6 +117,8 @@ class GraphedMiStep:
 
     def _fwd(self):
         p = self.params
+        if self.boundary == "bf16":
+            raise _hip.MiCriticError('boundary="bf16" has the one-call step only (step() / step_eager() / loss())')
         if self.kind == "bilinear":
             _hip.call("mi_bilinear_fwd", self.device, self.x.data_ptr(), self.y.data_ptr(), p[0].data_ptr() if p else None,
                       self.sid.data_ptr(), self.sid.data_ptr(), self.b, self.b, 0, self.dx, self.dy, self.est, self.prec, 1,
@@ -145,7 +160,12 @@ class GraphedMiStep:
         """Forward + backward as ONE C-ABI call where the library has one (bilinear critic: mi_bilinear_step, four launches
         and no finalize kernel); the two calls otherwise."""
         p, g = self.params, self.grad_params
-        if self.kind == "bilinear":
+        if self.boundary == "bf16":
+            _hip.call("mi_bilinear_step_bf16", self.device, self.x.data_ptr(), self.y.data_ptr(), p[0].data_ptr(),
+                      self.sid.data_ptr(), self.b, self.dx, self.dy, self.est, self.grad_out.data_ptr(),
+                      self.loss_buf.data_ptr(), self.stats.data_ptr(), self.record.data_ptr(), self.grad_x.data_ptr(),
+                      self.grad_y.data_ptr(), 1, g[0].data_ptr(), self.ws.data_ptr(), self.ws.numel())
+        elif self.kind == "bilinear":
             _hip.call("mi_bilinear_step", self.device, self.x.data_ptr(), self.y.data_ptr(), p[0].data_ptr() if p else None,
                       self.sid.data_ptr(), self.b, self.dx, self.dy, self.est, self.prec, self.grad_out.data_ptr(),
                       self.loss_buf.data_ptr(), self.stats.data_ptr(), self.record.data_ptr(), self.grad_x.data_ptr(),
@@ -160,22 +180,26 @@ class GraphedMiStep:
         side.wait_stream(torch.cuda.current_stream(self.device))
         with torch.cuda.stream(side):
             for _ in range(2):
-                self._fwd()
-                self._bwd()
+                if self.boundary != "bf16":
+                    self._fwd()
+                    self._bwd()
                 self._step()
         torch.cuda.current_stream(self.device).wait_stream(side)
         torch.cuda.synchronize(self.device)
         # thread_local: another thread's allocator traffic (a DataLoader's pin-memory thread) must not invalidate a capture
-        self.graph_fwd = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph_fwd, capture_error_mode="thread_local"):
-            self._fwd()
-        self.graph_bwd = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph_bwd, pool=self.graph_fwd.pool(), capture_error_mode="thread_local"):
-            self._bwd()
+        pool = None
+        if self.boundary != "bf16":
+            self.graph_fwd = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph_fwd, capture_error_mode="thread_local"):
+                self._fwd()
+            self.graph_bwd = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph_bwd, pool=self.graph_fwd.pool(), capture_error_mode="thread_local"):
+                self._bwd()
+            pool = self.graph_fwd.pool()
         # forward + backward as ONE graph for step(): a replay costs ~10 us of fixed overhead, more than the launches of a
         # short backward
         self.graph_step = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph_step, pool=self.graph_fwd.pool(), capture_error_mode="thread_local"):
+        with torch.cuda.graph(self.graph_step, pool=pool, capture_error_mode="thread_local"):
             self._step()
 
     # ------------------------------------------------------------------------------------------ replay
@@ -231,7 +255,10 @@ class _GraphedFn(torch.autograd.Function):
     def forward(ctx, step: GraphedMiStep, x, y, *params):
         step.x.copy_(x)
         step.y.copy_(y)
-        step.forward()
+        if step.boundary == "bf16":
+            step.step()  # one call computes the loss AND the gradients of 1 * loss; backward() scales them
+        else:
+            step.forward()
         ctx.step = step
         ctx.generation = step.generation
         return step.loss_buf.clone()
@@ -245,6 +272,10 @@ class _GraphedFn(torch.autograd.Function):
                 "ran on the same GraphedMiStep before this backward): its static inputs, workspace and statistics now "
                 "belong to the later batch.  Call backward() before the next forward, or use one GraphedMiStep per loss "
                 "that is alive at the same time (or mi_critics.fused_mi_bound, which keeps per-call state).")
+        if step.boundary == "bf16":
+            go = grad_loss.reshape(-1)[:1].float()
+            return (None, (step.grad_x.float() * go).to(step.grad_x.dtype), (step.grad_y.float() * go).to(step.grad_y.dtype),
+                    *[g * go for g in step.grad_params])
         step.grad_out.copy_(grad_loss.reshape(-1)[:1])
         step.backward()
         # clones: autograd may keep (or accumulate into) what it is handed, and the buffers are rewritten next step

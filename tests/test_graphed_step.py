@@ -140,3 +140,53 @@ def test_reference_encoders_end_to_end(dev, tmp_path):
     for needle in ("Epoch 2 loss = ", "Epoch 2 took ", "Epoch 2 checkpoint saved in ", "Image model saved in ", "Text model saved in "):
         assert needle in log
     assert tuple(next(mgr.mi_discriminator.parameters()).shape) == (1024, 768 + 64)   # make_mlp(d_img + d_txt, [1024, 512])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("b,d,est", [(4096, 512, "infonce"), (256, 128, "dv")])
+def test_bf16_boundary_equals_fp32_boundary(b, d, est):
+    """mi_bilinear_step_bf16 (bfloat16 embeddings in, bfloat16 dX / dY out): the kernels round fp32 embeddings to bf16 as
+    their first act, so on bf16-representable values the loss, the statistics and dW are BIT-identical to the fp32
+    boundary's, and dX / dY are its fp32 gradients rounded once to bf16.  Also against the oracle at the bf16 tolerances."""
+    import math
+    import torch
+    from mutual_info_img_txt import _hip
+    from mutual_info_img_txt.graphed import GraphedMiStep
+    from mutual_info_img_txt.model import BilinearCritic
+    from oracle import mi_oracle as orc
+    dev = torch.device("cuda:0")
+    gen = torch.Generator().manual_seed(b + d)
+    x = torch.randn(b, d, generator=gen).bfloat16()
+    y = torch.randn(b, d, generator=gen).bfloat16()
+    w = torch.randn(d, d, generator=gen) * (0.25 / math.sqrt(d))
+    sid = torch.arange(b)
+    sid[5] = sid[b - 7]
+    critic = BilinearCritic(d, d)
+    with torch.no_grad():
+        critic.weight.copy_(w)
+    critic.to(dev)
+    s32 = GraphedMiStep(critic, b, d, d, est, "bf16", dev, capture=False)
+    s16 = GraphedMiStep(critic, b, d, d, est, "bf16", dev, capture=True, boundary="bf16")
+    s32.set_inputs(x.float().to(dev), y.float().to(dev), sid)
+    s16.set_inputs(x.to(dev), y.to(dev), sid)
+    l32 = s32.step_eager().clone()
+    for mode in ("eager", "graph"):
+        l16 = (s16.step_eager() if mode == "eager" else s16.step()).clone()
+        torch.cuda.synchronize()
+        assert torch.equal(l16, l32), (mode, float(l16), float(l32))
+        assert torch.equal(s16.stats, s32.stats)
+        assert torch.equal(s16.grad_params[0], s32.grad_params[0])
+        assert s16.grad_x.dtype == torch.bfloat16 and s16.grad_y.dtype == torch.bfloat16
+        assert torch.equal(s16.grad_x, s32.grad_x.bfloat16()) and torch.equal(s16.grad_y, s32.grad_y.bfloat16())
+    o = orc.bilinear_step_rounded(x.float(), y.float(), w, sid, est)
+    assert abs(float(l16.sum()) - float(o["loss"].sum())) < 2e-3 * max(1.0, float(o["scores"].abs().max()))
+    for got, ref in ((s16.grad_x, o["dx"]), (s16.grad_y, o["dy"]), (s16.grad_params[0], o["dw"])):
+        assert float((got.cpu().double() - ref).abs().max()) < 1.2e-2 * float(ref.abs().max())
+    # the autograd-connected form
+    xl, yl = x.to(dev).requires_grad_(True), y.to(dev).requires_grad_(True)
+    loss = s16.loss(xl, yl, sid)
+    (2.0 * loss.sum()).backward()
+    assert xl.grad.dtype == torch.bfloat16
+    assert float((xl.grad.float() - 2.0 * s32.grad_x).abs().max()) <= 2.0 ** -7 * float(s32.grad_x.abs().max()) * 2.0
+    with pytest.raises(ValueError):
+        GraphedMiStep(critic, b, d, d, est, "f32", dev, capture=False, boundary="bf16")
