@@ -183,6 +183,12 @@ int mi_bilinear_bwd_records(const float* x, const float* y, const float* w, cons
                             int64_t d_txt, int precision, int estimator, const float* records, int64_t n_records,
                             int64_t n_pos, const float* grad_out, float* loss_out, mi_stats* stats_out, float* grad_x,
                             float* grad_y, float* grad_w, void* workspace, size_t workspace_bytes, void* stream);
+/* mi_bilinear_bwd_records with grad_w == NULL stops after its first launch (statistics, loss, grad_x, the partial grad_y);
+ * mi_bilinear_bwd_dw then launches dW = X^T dT from the same workspace.  Between the two a sharded step starts the
+ * reduce-scatter of grad_y, which so overlaps the dW launch (ABI 4). */
+int mi_bilinear_bwd_dw(int64_t b_rows, int64_t b, int64_t d_img, int64_t d_txt, int precision, float* grad_w,
+                       void* workspace, size_t workspace_bytes, void* stream);
+
 
 /* fp8 mode (MI_PREC_FP8) on a sharded batch: the per-tensor scales must be the whole batch's.  The forward's preparation
  * in three stages around the caller's two MAX all-reduces of amax_io (4 floats on the device: x, y, w, T):
@@ -236,6 +242,14 @@ int mi_separable_bwd(const float* x, const float* y, const float* wg, const floa
                      int64_t d_txt, int64_t d_proj, int precision, const mi_stats* stats, const float* grad_out,
                      float* grad_x, float* grad_y, float* grad_wg, float* grad_wh, void* workspace,
                      size_t workspace_bytes, int workspace_from_forward, void* stream);
+
+/* One separable-critic step in one call (single GPU; ABI 4): as mi_bilinear_step.  Five launches where the fused kernels
+ * take the shape (mi_separable_path == MI_PATH_FUSED_TAIL): conversions, the two projections, the fused B x B kernel,
+ * [statistics + dA, dC rows + dX, dY on the matrix cores], [dWg | dWh]. */
+int mi_separable_step(const float* x, const float* y, const float* wg, const float* wh, const int64_t* sid, int64_t b,
+                      int64_t d_img, int64_t d_txt, int64_t d_proj, int estimator, int precision, const float* grad_out,
+                      float* loss_out, mi_stats* stats, float* partials_out, float* grad_x, float* grad_y,
+                      float* grad_wg, float* grad_wh, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- fused concat-MLP critic (the reference's mi_discriminator) ------------------------------------ */
 /* params in PyTorch [out,in] layout: w1 [h1, d_img+d_txt], b1 [h1], w2 [h2, h1], b2 [h2], w3 [h2], b3 [1]. */

@@ -267,6 +267,7 @@ static int bilinear_tail(int64_t br, int64_t b, int64_t row_offset, int64_t dx, 
   int rc = launch_flash_tail(ta, dy, p.fl.slab_f16, merge != nullptr, st,
                              merge ? "bilinear sums -> loss, dT, dY | dX = dT W^T" : "bilinear sums -> dT, dY | dX = dT W^T");
   if (rc) return rc;
+  if (!grad_w) return MI_OK;  // the caller launches dW itself (mi_bilinear_bwd_dw), e.g. behind the start of a reduce-scatter
   return launch_bilinear_dw(DwArgs{p.xtfb, p.dttfb, dx, dy, br, grad_w}, st, "bilinear dW = X^T dT");
 }
 
@@ -689,7 +690,7 @@ int mi_bilinear_bwd_records(const float* x, const float* y, const float* w, cons
                             int64_t d_txt, int precision, int estimator, const float* records, int64_t n_records,
                             int64_t n_pos, const float* grad_out, float* loss_out, mi_stats* stats_out, float* grad_x,
                             float* grad_y, float* grad_w, void* workspace, size_t workspace_bytes, void* stream) {
-  MI_CHECK_ARG(x && y && w && sid_rows && sid_cols && records && stats_out && grad_x && grad_y && grad_w && workspace,
+  MI_CHECK_ARG(x && y && w && sid_rows && sid_cols && records && stats_out && grad_x && grad_y && workspace,
                "mi_bilinear_bwd_records: null pointer");
   MI_CHECK_ARG(n_records > 0 && n_pos > 0, "mi_bilinear_bwd_records: n_records and n_pos must be positive");
   MI_CHECK_ARG(estimator == MI_DV || estimator == MI_INFONCE, "mi_bilinear_bwd_records: unknown estimator %d", estimator);
@@ -708,6 +709,28 @@ int mi_bilinear_bwd_records(const float* x, const float* y, const float* w, cons
   TailMerge tm{estimator, loss_out, stats_out, nullptr, records, n_records, n_pos};
   return bilinear_tail(b_rows, b, row_offset, d_img, d_txt, nullptr, grad_out, grad_x, grad_y, grad_w, p, &tm,
                        (hipStream_t)stream);
+}
+
+/* The second launch of the backward's tail on its own (dW = X^T dT from the fragment-major operands the first launch and
+ * the forward left in the workspace).  For callers that ran mi_bilinear_bwd_records with grad_w == NULL: the reduce-scatter
+ * of grad_y only needs the first launch, so a sharded step starts it (on RCCL's stream) BEFORE this launch and the two
+ * overlap. */
+int mi_bilinear_bwd_dw(int64_t b_rows, int64_t b, int64_t d_img, int64_t d_txt, int precision, float* grad_w,
+                       void* workspace, size_t workspace_bytes, void* stream) {
+  MI_CHECK_ARG(grad_w && workspace, "mi_bilinear_bwd_dw: null pointer");
+  int rc = check_common("mi_bilinear_bwd_dw", b_rows, b, 0, d_img, d_txt, precision);
+  if (rc) return rc;
+  Workspace ws(workspace, workspace_bytes);
+  BilinearPlan p = plan_bilinear(ws, b_rows, b, d_img, d_txt, precision);
+  if (!ws.ok()) {
+    set_error("mi_bilinear_bwd_dw: workspace too small (%zu < %zu)", workspace_bytes, ws.off);
+    return MI_EWORKSPACE;
+  }
+  if (!(fast_ok(b_rows, b, d_img, d_txt, precision, true) && p.fl.ok && p.tail)) {
+    set_error("mi_bilinear_bwd_dw: shape / precision outside the fused kernels");
+    return MI_ESHAPE;
+  }
+  return launch_bilinear_dw(DwArgs{p.xtfb, p.dttfb, d_img, d_txt, b_rows, grad_w}, (hipStream_t)stream, "bilinear dW = X^T dT");
 }
 
 /* Sharded batches: the part of the forward's preparation that depends on the rank's OWN rows only -- the bf16 copies of
@@ -890,6 +913,10 @@ struct SeparablePlan {
   float *wg_slab, *wh_slab;
   int wg_splits, wh_splits;
   int64_t wg_kchunk, wh_kchunk;
+  // the two-launch backward tail (mi_bilinear_tail.h, round 4): fragment-major Wg, Wh (B operands of dX = dA Wg^T and
+  // dY = dC Wh^T inside the tail kernel), X^T, Y^T, dA^T, dC^T (operands of the one dWg | dWh launch)
+  bool tail;
+  bf16_t *gfb, *hfb, *xtfb, *ytfb, *datfb, *dctfb;
   // generic path
   float *a32, *c32, *da32, *dc32;
   void* g;
@@ -938,6 +965,16 @@ static SeparablePlan plan_separable(Workspace& ws, int64_t br, int64_t b, int64_
     split_plan(b, dy, k, p.wh_splits, p.wh_kchunk);
     p.wg_slab = ws.take<float>((int64_t)p.wg_splits * dx * k);
     p.wh_slab = ws.take<float>((int64_t)p.wh_splits * dy * k);
+    static const bool no_tail = getenv("MI_NO_TAIL") != nullptr;  // A/B switch, as for the bilinear critic
+    p.tail = !no_tail && flash_tail_ok(br, dx, k) && flash_tail_ok(b, dy, k) && p.fl.slab_f16;
+    if (p.tail) {
+      p.gfb = ws.take<bf16_t>(dx * k);
+      p.hfb = ws.take<bf16_t>(dy * k);
+      p.xtfb = ws.take<bf16_t>(br * dx);
+      p.ytfb = ws.take<bf16_t>(b * dy);
+      p.datfb = ws.take<bf16_t>(br * k);
+      p.dctfb = ws.take<bf16_t>(b * k);
+    }
   } else {
     p.a32 = ws.take<float>(br * k);
     p.c32 = ws.take<float>(b * k);
@@ -957,10 +994,10 @@ static int separable_prep_project(const float* x, const float* y, const float* w
                                   int64_t row_offset, int64_t dx, int64_t dy, int64_t k, const SeparablePlan& p,
                                   hipStream_t st) {
   CvtJobs jobs{};
-  jobs.j[0] = CvtJob{x, br, dx, p.xb, p.xtb, 0, 0, nullptr};
-  jobs.j[1] = CvtJob{y, b, dy, p.yb, p.ytb, 0, 0, nullptr};
-  jobs.j[2] = CvtJob{wg, dx, k, p.gb, p.gtb, 0, 0, nullptr};
-  jobs.j[3] = CvtJob{wh, dy, k, p.hb, p.htb, 0, 0, nullptr};
+  jobs.j[0] = CvtJob{x, br, dx, p.xb, p.xtb, 0, 0, nullptr, 0, 0, p.tail ? p.xtfb : nullptr};
+  jobs.j[1] = CvtJob{y, b, dy, p.yb, p.ytb, 0, 0, nullptr, 0, 0, p.tail ? p.ytfb : nullptr};
+  jobs.j[2] = CvtJob{wg, dx, k, p.gb, p.gtb, 0, 0, p.tail ? p.gfb : nullptr};
+  jobs.j[3] = CvtJob{wh, dy, k, p.hb, p.htb, 0, 0, p.tail ? p.hfb : nullptr};
   jobs.dup = DupFlagJob{sid_rows, sid_cols, (int)(br / 32), (int)(b / 32), p.dup[0], p.dup[1], row_offset};
   int rc = launch_cvt_transpose3(jobs, st, "separable prep X Y Wg Wh");
   if (rc) return rc;
@@ -1152,11 +1189,66 @@ int mi_separable_bwd(const float* x, const float* y, const float* wg, const floa
 
 }  // extern "C"
 
+/* One separable-critic step in ONE call (single GPU): prep, projections, the fused B x B kernel, then the two-launch tail
+ * of the bilinear critic generalised to two products -- [records -> statistics and loss; partial sums -> dA, dC rows; dX =
+ * dA Wg^T, dY = dC Wh^T on the matrix cores; dA^T, dC^T fragment-major] and [dWg = X^T dA | dWh = Y^T dC] -- five launches
+ * (round 3: eight, with a finalize, a slab-reduce and two split-K reduce launches).  Shapes outside the fused kernels: the
+ * forward and the backward entry points, one after the other. */
+extern "C" int mi_separable_step(const float* x, const float* y, const float* wg, const float* wh, const int64_t* sid,
+                                 int64_t b, int64_t d_img, int64_t d_txt, int64_t d_proj, int estimator, int precision,
+                                 const float* grad_out, float* loss_out, mi_stats* stats, float* partials_out, float* grad_x,
+                                 float* grad_y, float* grad_wg, float* grad_wh, void* workspace, size_t workspace_bytes,
+                                 void* stream) {
+  using namespace mi;
+  MI_CHECK_ARG(x && y && wg && wh && sid && stats && grad_x && grad_y && grad_wg && grad_wh && workspace,
+               "mi_separable_step: null pointer");
+  int rc = check_separable("mi_separable_step", b, b, 0, d_img, d_txt, d_proj, precision);
+  if (rc) return rc;
+  MI_CHECK_ARG(estimator == MI_DV || estimator == MI_INFONCE, "mi_separable_step: unknown estimator %d", estimator);
+  Workspace ws(workspace, workspace_bytes);
+  SeparablePlan p = plan_separable(ws, b, b, d_img, d_txt, d_proj, precision);
+  if (!ws.ok()) {
+    set_error("mi_separable_step: workspace too small (%zu < %zu)", workspace_bytes, ws.off);
+    return MI_EWORKSPACE;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  if (p.fast && p.tail) {
+    rc = separable_prep_project(x, y, wg, wh, sid, sid, b, b, 0, d_img, d_txt, d_proj, p, st);
+    if (rc) return rc;
+    rc = separable_flash(sid, sid, b, b, 0, d_proj, true, p, st);
+    if (rc) return rc;
+    FlashTailArgs ta{};
+    ta.j[0] = FlashReduceJob{p.slab[0], p.rec[0], p.fl.n_split[0], p.fl.n_rb[0], b, p.cb, b, 0, nullptr, nullptr, nullptr};
+    ta.j[1] = FlashReduceJob{p.slab[1], p.rec[1], p.fl.n_split[1], p.fl.n_rb[1], b, p.ab, b, 0, nullptr, nullptr, nullptr};
+    ta.stats = stats;
+    ta.grad_out = grad_out;
+    ta.merge_rec = p.rec[0];
+    ta.n_merge = p.fl.n_rec[0];
+    ta.n_pos = b;
+    ta.estimator = estimator;
+    ta.loss_out = loss_out;
+    ta.stats_out = stats;
+    ta.partials_out = partials_out;
+    ta.w_frag = p.gfb;  ta.dx = d_img;  ta.grad_x = grad_x;  ta.dtt_frag = p.datfb;
+    ta.w_frag1 = p.hfb; ta.dx1 = d_txt; ta.grad_x1 = grad_y; ta.dtt_frag1 = p.dctfb;
+    rc = launch_flash_tail(ta, d_proj, p.fl.slab_f16, true, st, "separable sums -> loss, dA, dC | dX = dA Wg^T | dY = dC Wh^T");
+    if (rc) return rc;
+    const DwArgs g{p.xtfb, p.datfb, d_img, d_proj, b, grad_wg}, h{p.ytfb, p.dctfb, d_txt, d_proj, b, grad_wh};
+    return launch_bilinear_dw(g, st, "separable dWg = X^T dA | dWh = Y^T dC", &h);
+  }
+  rc = mi_separable_fwd(x, y, wg, wh, sid, sid, b, b, 0, d_img, d_txt, d_proj, estimator, precision, 1, loss_out, stats,
+                        partials_out, workspace, workspace_bytes, stream);
+  if (rc) return rc;
+  return mi_separable_bwd(x, y, wg, wh, sid, sid, b, b, 0, d_img, d_txt, d_proj, precision, stats, grad_out, grad_x, grad_y,
+                          grad_wg, grad_wh, workspace, workspace_bytes, 1, stream);
+}
+
 extern "C" int mi_separable_path(int64_t b_rows, int64_t b, int64_t d_img, int64_t d_txt, int64_t d_proj, int precision) {
   if (b_rows <= 0 || b <= 0 || d_img <= 0 || d_txt <= 0 || d_proj <= 0) return MI_EINVAL;
   char* fake = reinterpret_cast<char*>(uintptr_t(1) << 20);
   mi::Workspace ws(fake, ~size_t(0) >> 1);
-  return mi::plan_separable(ws, b_rows, b, d_img, d_txt, d_proj, precision).fast ? MI_PATH_FUSED : MI_PATH_GENERIC;
+  const mi::SeparablePlan p = mi::plan_separable(ws, b_rows, b, d_img, d_txt, d_proj, precision);
+  return p.fast ? (p.tail ? MI_PATH_FUSED_TAIL : MI_PATH_FUSED) : MI_PATH_GENERIC;
 }
 
 #ifdef MI_STAMPS

@@ -40,6 +40,12 @@ struct FlashTailArgs {
   bf16_t* grad_x_bf;         // [m0][dx] bf16 instead (the bf16 boundary: mi_bilinear_step_bf16) or null
   bf16_t* dtt_frag;          // dT^T [D][m0] fragment-major: block (c / 32, i / 16); operand of bilinear_dw_kernel
   int n_blocks0;             // 32-row blocks of job 0 (they come first in the grid: the longer ones)
+  // the same product for job 1 (separable critic: dY = dC Wh^T and dC^T for dWh; null for the bilinear critic, whose job 1
+  // writes grad_y rows directly)
+  const bf16_t* w_frag1;
+  int64_t dx1;
+  float* grad_x1;
+  bf16_t* dtt_frag1;
 };
 
 constexpr int kTailPad = 4;  // floats of padding per LDS row: 16-byte row reads conflict-free, column reads too
@@ -266,7 +272,7 @@ __global__ __launch_bounds__(kTailThreads, 2) void flash_tail_kernel(FlashTailAr
         const bf16x8 o = oth[g];
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] -= gpos * (float)o[e];
-        if (job == 0) {
+        if (job == 0 || args.w_frag1 != nullptr) {  // the tile feeds the product below
 #pragma unroll
           for (int e = 0; e < 8; ++e) tile[row][c + e] = v[e];
         }
@@ -283,7 +289,16 @@ __global__ __launch_bounds__(kTailThreads, 2) void flash_tail_kernel(FlashTailAr
       }
     }
   }
-  if (job != 0 || (GBF ? args.grad_x_bf == nullptr : args.grad_x == nullptr)) return;
+  if (job != 0) {
+    if (GBF || args.w_frag1 == nullptr) return;
+  } else if (GBF ? args.grad_x_bf == nullptr : args.grad_x == nullptr) {
+    return;
+  }
+  // (scalar selects: job is workgroup-uniform)
+  const bf16_t* const w_frag = job ? args.w_frag1 : args.w_frag;
+  const int64_t dx_out = job ? args.dx1 : args.dx;
+  float* const gx_out = job ? args.grad_x1 : args.grad_x;
+  bf16_t* const dtt_out = job ? args.dtt_frag1 : args.dtt_frag;
   __syncthreads();
 
   // ---- dX[i0 .. +32][a] = sum_c dT[i][c] W[a][c]: A = the dT tile (rows on the lane; bf16 from LDS), B = W fragments
@@ -291,7 +306,7 @@ __global__ __launch_bounds__(kTailThreads, 2) void flash_tail_kernel(FlashTailAr
   // The W loads go out first: dT^T below is written under their latency.
   constexpr int NK = D / 16;
   const int r = lane & 31, h = lane >> 5;
-  const int64_t n_at = args.dx / 32;  // 32-column tiles of dX
+  const int64_t n_at = dx_out / 32;  // 32-column tiles of dX
   constexpr int PF = 8;               // k-steps of W fragments in flight
   bf16x8 bq[PF][2];
   const bf16_t* wbase[2];
@@ -300,7 +315,7 @@ __global__ __launch_bounds__(kTailThreads, 2) void flash_tail_kernel(FlashTailAr
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
       const int64_t at = at0 + t < n_at ? at0 + t : n_at - 1;
-      wbase[t] = args.w_frag + (at * NK * 64 + lane) * 8;
+      wbase[t] = w_frag + (at * NK * 64 + lane) * 8;
     }
 #pragma unroll
     for (int p = 0; p < PF; ++p)
@@ -319,7 +334,7 @@ __global__ __launch_bounds__(kTailThreads, 2) void flash_tail_kernel(FlashTailAr
       bf16x8 o;
 #pragma unroll
       for (int jj = 0; jj < 8; ++jj) o[jj] = (bf16_t)tile[16 * kl + 8 * h + jj][32 * cb + r];
-      *reinterpret_cast<bf16x8*>(args.dtt_frag + (((int64_t)cb * nkb + (i0 / 16 + kl)) * 64 + lane) * 8) = o;
+      *reinterpret_cast<bf16x8*>(dtt_out + (((int64_t)cb * nkb + (i0 / 16 + kl)) * 64 + lane) * 8) = o;
     }
   }
 
@@ -333,7 +348,7 @@ __global__ __launch_bounds__(kTailThreads, 2) void flash_tail_kernel(FlashTailAr
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
         const int64_t at = at0 + t < n_at ? at0 + t : n_at - 1;
-        wbase[t] = args.w_frag + (at * NK * 64 + lane) * 8;
+        wbase[t] = w_frag + (at * NK * 64 + lane) * 8;
       }
 #pragma unroll
       for (int p = 0; p < PF; ++p)
@@ -361,9 +376,9 @@ __global__ __launch_bounds__(kTailThreads, 2) void flash_tail_kernel(FlashTailAr
       for (int g = 0; g < 4; ++g)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const int64_t o = (i0 + 8 * g + 4 * h + e) * args.dx + (at0 + t) * 32 + r;
+          const int64_t o = (i0 + 8 * g + 4 * h + e) * dx_out + (at0 + t) * 32 + r;
           if constexpr (GBF) args.grad_x_bf[o] = (bf16_t)acc[t][4 * g + e];
-          else args.grad_x[o] = acc[t][4 * g + e];
+          else gx_out[o] = acc[t][4 * g + e];
         }
     }
   }
@@ -421,13 +436,20 @@ struct DwArgs {
 
 constexpr int kDwWaves = 8;  // the batch dimension is split over the waves of a workgroup (one workgroup per CU: the loads
                              // a CU keeps in flight are this workgroup's)
-static __global__ __launch_bounds__(64 * kDwWaves, 1) void bilinear_dw_kernel(DwArgs a) {
+struct DwArgs2 {
+  DwArgs p[2];
+  int n_tiles0;  // workgroups of problem 0 (they come first)
+};
+static __global__ __launch_bounds__(64 * kDwWaves, 1) void bilinear_dw_kernel(DwArgs2 a2) {
   __shared__ float part[kDwWaves - 1][32][33];
+  const int prob = (int)blockIdx.x >= a2.n_tiles0 ? 1 : 0;
+  const DwArgs& a = a2.p[prob];
+  const int64_t tile_id = prob ? (int64_t)blockIdx.x - a2.n_tiles0 : (int64_t)blockIdx.x;
   // (readfirstlane: the wave index must be a SCALAR for hipcc -- an MFMA ignores EXEC, so a matrix instruction under a
   // condition hipcc takes for divergent, and lowers to an EXEC mask without a skip branch, would still execute)
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int64_t nct = a.dy / 32;
-  const int64_t at = blockIdx.x / nct, ct = blockIdx.x % nct;
+  const int64_t at = tile_id / nct, ct = tile_id % nct;
   const int64_t nkb = a.k / 16;                 // 16-deep blocks over the batch
   const int64_t kb0 = nkb * wave / kDwWaves, kb1 = nkb * (wave + 1) / kDwWaves;
   const bf16_t* ap = a.xt_frag + ((at * nkb + kb0) * 64 + lane) * 8;
@@ -478,11 +500,16 @@ static __global__ __launch_bounds__(64 * kDwWaves, 1) void bilinear_dw_kernel(Dw
   }
 }
 
-static inline int launch_bilinear_dw(const DwArgs& a, hipStream_t st, const char* what) {
-  const unsigned grid = (unsigned)((a.dx / 32) * (a.dy / 32));
+// one launch for up to two products (the separable critic's dWg and dWh); b == null: one
+static inline int launch_bilinear_dw(const DwArgs& a, hipStream_t st, const char* what, const DwArgs* b = nullptr) {
+  DwArgs2 a2{};
+  a2.p[0] = a;
+  a2.p[1] = b ? *b : a;
+  a2.n_tiles0 = (int)((a.dx / 32) * (a.dy / 32));
+  const unsigned grid = (unsigned)(a2.n_tiles0 + (b ? (b->dx / 32) * (b->dy / 32) : 0));
   {
     ProfScope prof_(what, st);
-    hipLaunchKernelGGL(bilinear_dw_kernel, dim3(grid), dim3(64 * kDwWaves), 0, st, a);
+    hipLaunchKernelGGL(bilinear_dw_kernel, dim3(grid), dim3(64 * kDwWaves), 0, st, a2);
   }
   MI_LAUNCH_CHECK(what);
   return MI_OK;

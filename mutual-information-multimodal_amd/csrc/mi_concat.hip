@@ -31,6 +31,9 @@ struct ConcatPlan {
   f16_t *uh, *vh, *w2h, *vht;
   unsigned* upk;
   F16Scales* f16sc;
+  // two-part fp16 mode (MI_PREC_F16X3): scaled fp32 copies of U, V and the interleaved [hi | lo] copy of W2
+  float *us, *vs;
+  f16_t* w2x;
   Partial* partials;
   unsigned long long* bitsP;
   unsigned* bitsN;
@@ -67,11 +70,17 @@ static ConcatPlan plan_concat(Workspace& ws, int64_t br, int64_t b, int64_t h1, 
     p.upk = need_grad ? ws.take<unsigned>(br * h1) : nullptr;
     p.vht = need_grad ? ws.take<f16_t>(b * h1) : nullptr;
   }
+  if (precision == MI_PREC_F16X3) {
+    p.us = ws.take<float>(br * h1);
+    p.vs = ws.take<float>(b * h1);
+    p.w2x = ws.take<f16_t>(2 * h2 * h1);
+    p.f16sc = ws.take<F16Scales>(1);
+  }
   p.partials = ws.take<Partial>(kMatrixPartialBlocks);
   if (need_grad) {
     p.bitsP = ws.take<unsigned long long>(bitsp_words(br, b, h2));
     p.bitsN = ws.take<unsigned>(br * ((b + 31) / 32) * h2);
-    const bool op16 = precision == MI_PREC_BF16 || precision == MI_PREC_F16;
+    const bool op16 = precision == MI_PREC_BF16 || precision == MI_PREC_F16 || precision == MI_PREC_F16X3;
     const int kc = op16 ? DuvCfg<bf16_t>::KC : DuvCfg<float>::KC;
     const int64_t n_kc = (h1 + kc - 1) / kc;
     p.n_iblk = (int)((br + kDuvTI - 1) / kDuvTI);
@@ -89,7 +98,7 @@ static ConcatPlan plan_concat(Workspace& ws, int64_t br, int64_t b, int64_t h1, 
     int64_t rpm = (br + 1023) / 1024;
     p.rows_per_msplit = (int)rpm;
     p.n_msplit = (int)((br + rpm - 1) / rpm);
-    if (op16) p.w2wp = ws.take<bf16_t>(h1 * h2);
+    if (op16) p.w2wp = ws.take<bf16_t>((precision == MI_PREC_F16X3 ? 2 : 1) * h1 * h2);  // F16X3: hi and lo parts
     else p.w2wp = ws.take<float>(h1 * h2);
     p.du_slab = ws.take<float>((int64_t)p.n_jsplit * br * h1);
     p.dv_slab = ws.take<float>((int64_t)p.n_iblk * b * h1);
@@ -122,8 +131,8 @@ static int check_concat_shape(const char* fn, int64_t br, int64_t b, int64_t row
   MI_CHECK_ARG(br >= 1 && b >= 1 && br <= b, "%s: need 1 <= b_rows <= b", fn);
   MI_CHECK_ARG(row_offset >= 0 && row_offset + br <= b, "%s: row block outside [0, b)", fn);
   MI_CHECK_ARG(dx >= 1 && dy >= 1, "%s: embedding widths must be >= 1", fn);
-  MI_CHECK_ARG(precision == MI_PREC_F32 || precision == MI_PREC_BF16 || precision == MI_PREC_F16,
-               "%s: precision %d is not one of MI_PREC_F32, MI_PREC_BF16, MI_PREC_F16", fn, precision);
+  MI_CHECK_ARG(precision == MI_PREC_F32 || precision == MI_PREC_BF16 || precision == MI_PREC_F16 || precision == MI_PREC_F16X3,
+               "%s: precision %d is not one of MI_PREC_F32, MI_PREC_BF16, MI_PREC_F16, MI_PREC_F16X3", fn, precision);
   if (h1 < 64 || h1 % 64 != 0 || h2 < 256 || h2 % 256 != 0 || h2 > 512) {
     set_error("%s: the fused kernels need h1 %% 64 == 0 and h2 in {256, 512} (got h1=%lld, h2=%lld)", fn, (long long)h1,
               (long long)h2);
@@ -179,7 +188,7 @@ static int launch_concat_fwd(const float* u, const float* v, const OpT* w2, cons
 }
 
 // OpT = float (exact fp32 products), bf16_t, or f16_t (mi_concat_f16.h: scaled fp16 operands, packed generation)
-template <typename OpT>
+template <typename OpT, bool X3 = false>
 static int concat_bwd_impl(const float* x, const float* y, const float* w1, const float* w2, const float* b2,
                            const float* w3, const int64_t* sid_rows, const int64_t* sid_cols, int64_t br, int64_t b,
                            int64_t row_offset, int64_t dx, int64_t dy, int h1, int h2, const mi_stats* stats,
@@ -191,7 +200,9 @@ static int concat_bwd_impl(const float* x, const float* y, const float* w1, cons
   OpT* w2wp = (OpT*)p.w2wp;
   {
     ProfScope prof_("prep_w2w_kernel", st);
-    if constexpr (kF16) {
+    if constexpr (X3) {
+      hipLaunchKernelGGL(f16x3_prep_w2w_kernel, dim3(512), dim3(256), 0, st, w2, w3, h1, h2, (const F16Scales*)p.f16sc, w2wp);
+    } else if constexpr (kF16) {
       hipLaunchKernelGGL(f16_prep_w2w_kernel, dim3(512), dim3(256), 0, st, w2, w3, h1, h2, (const F16Scales*)p.f16sc, w2wp);
     } else {
       hipLaunchKernelGGL(prep_w2w_kernel<OpT>, dim3(512), dim3(256), 0, st, w2, w3, h1, h2, w2wp);
@@ -210,11 +221,18 @@ static int concat_bwd_impl(const float* x, const float* y, const float* w1, cons
     // each); MI_DUV_OLD=1 keeps the first kernel (A/B)
     static const bool duv_old = getenv("MI_DUV_OLD") != nullptr;
     if constexpr (sizeof(OpT) == 2) {
-      if (!duv_old && (h2 % 128) == 0) {
-        const size_t smem3 = Duv3Smem::total(h2);
+      if ((!duv_old || X3) && (h2 % 128) == 0) {
+        const size_t smem3 = Duv3Smem::total(h2, X3);
         const dim3 grid3(xcd_grid((h1 + Duv3Smem::KC - 1) / Duv3Smem::KC, (int64_t)p.n_iblk * p.n_jsplit));
         const F16Scales* scp = kF16 ? (const F16Scales*)p.f16sc : (const F16Scales*)nullptr;
-        if constexpr (kF16) {
+        if constexpr (X3) {
+          MI_SET_DYN_SMEM((concat_bwd_duv3_kernel<f16_t, float, true>), smem3, "hipFuncSetAttribute(concat_bwd_duv3_kernel)");
+          ProfScope prof_("concat_bwd_duv_kernel", st);
+          hipLaunchKernelGGL((concat_bwd_duv3_kernel<f16_t, float, true>), grid3, dim3(256), smem3, st, (const float*)p.u,
+                             (const float*)p.v, (const f16_t*)w2wp, (const unsigned long long*)p.bitsP, scores, sid_rows,
+                             sid_cols, stats, grad_out, br, b, row_offset, h1, h2, p.cols_per_split, xcd_natural(),
+                             p.du_slab, p.dv_slab, scp);
+        } else if constexpr (kF16) {
           MI_SET_DYN_SMEM((concat_bwd_duv3_kernel<f16_t, f16_t>), smem3, "hipFuncSetAttribute(concat_bwd_duv3_kernel)");
           ProfScope prof_("concat_bwd_duv_kernel", st);
           hipLaunchKernelGGL((concat_bwd_duv3_kernel<f16_t, f16_t>), grid3, dim3(256), smem3, st, (const f16_t*)p.uh,
@@ -263,7 +281,14 @@ static int concat_bwd_impl(const float* x, const float* y, const float* w1, cons
   // ---- D = sum_p M g H1  ->  dW2, dW3, db2, db3 --------------------------------------------------------------------
   {
     dim3 grid(xcd_grid(((h1 + 255) / 256) * (h2 / 256), p.n_dsplit));
-    if constexpr (kF16) {
+    if constexpr (X3) {
+      const size_t smem = (256 * 36 + kDw2IB * 32) * sizeof(float) + 256 * sizeof(bf16x8);
+      MI_SET_DYN_SMEM((concat_bwd_dw2_kernel<f16_t, true>), smem, "hipFuncSetAttribute(concat_bwd_dw2_kernel)");
+      ProfScope prof_("concat_bwd_dw2_kernel", st);
+      hipLaunchKernelGGL((concat_bwd_dw2_kernel<f16_t, true>), grid, dim3(512), smem, st, (const float*)p.us,
+                         (const float*)p.vs, (const unsigned*)p.bitsN, scores, sid_rows, sid_cols, stats, grad_out, br, b,
+                         row_offset, h1, h2, p.rows_per_dsplit, xcd_natural(), p.d_slab);
+    } else if constexpr (kF16) {
       MI_SET_DYN_SMEM(concat_bwd_dw2_f16_kernel, Dw2F16Smem::TOTAL, "hipFuncSetAttribute(concat_bwd_dw2_f16_kernel)");
       ProfScope prof_("concat_bwd_dw2_kernel", st);
       hipLaunchKernelGGL(concat_bwd_dw2_f16_kernel, grid, dim3(512), Dw2F16Smem::TOTAL, st, (const unsigned*)p.upk,
@@ -292,7 +317,7 @@ static int concat_bwd_impl(const float* x, const float* y, const float* w1, cons
       hipLaunchKernelGGL(concat_bwd_finish_w2_kernel, dim3((unsigned)h2), dim3(256), 0, st, (const float*)p.d_slab,
                          p.n_dsplit, (const float*)p.m_slab, (const float*)p.g_sum, p.n_msplit, w2, b2, w3, h1, h2,
                          grad_w2, grad_w3, grad_b2, grad_b3, kF16 ? (const F16Scales*)p.f16sc : (const F16Scales*)nullptr,
-                         grad_out);
+                         grad_out, stats, X3 ? 1 : 0);
     }
     MI_LAUNCH_CHECK("concat_bwd_finish_w2_kernel");
   }
@@ -374,7 +399,33 @@ int mi_concat_mlp_fwd(const float* x, const float* y, const float* w1, const flo
   if (rc) return rc;
   unsigned long long* bitsP = need_grad ? p.bitsP : nullptr;
   unsigned* bitsN = need_grad ? p.bitsN : nullptr;
-  if (precision == MI_PREC_F16) {
+  if (precision == MI_PREC_F16X3) {
+    // the fp32-tolerance mode: scaled fp32 U, V, two-part fp16 W2, three MFMAs per product (mi_concat_f16.h)
+    const hipError_t e0 = hipMemsetAsync(p.f16sc, 0, sizeof(F16Scales), st);
+    if (e0 != hipSuccess) return hip_fail(e0, "hipMemsetAsync(fp16 scales)");
+    F16AbsmaxJobs aj{{p.u, p.v, w2, w3}, {b_rows * h1, b * h1, h2 * h1, h2}, p.f16sc};
+    {
+      ProfScope prof_("f16 absmax U V W2 w3", st);
+      hipLaunchKernelGGL(f16_absmax_kernel, dim3(128, 4), dim3(256), 0, st, aj);
+    }
+    MI_LAUNCH_CHECK("f16_absmax_kernel");
+    F16X3PrepArgs pa{p.u, p.v, w2, b_rows, b, (int)h1, (int)h2, p.f16sc, p.us, p.vs, p.w2x};
+    {
+      ProfScope prof_("f16x3 prep Us Vs W2x", st);
+      hipLaunchKernelGGL(f16x3_prep_kernel, dim3(1024), dim3(256), 0, st, pa);
+    }
+    MI_LAUNCH_CHECK("f16x3_prep_kernel");
+    const dim3 grid1d((unsigned)(8 * (((b + kFwdTJ - 1) / kFwdTJ + 7) / 8) * ((b_rows + kFwdTI - 1) / kFwdTI)));
+    MI_SET_DYN_SMEM(concat_fwd_f16x3_kernel, FwdF16Smem::TOTAL, "hipFuncSetAttribute(concat_fwd_f16x3_kernel)");
+    {
+      ProfScope prof_("concat_fwd_kernel", st);
+      hipLaunchKernelGGL(concat_fwd_f16x3_kernel, grid1d, dim3(256), FwdF16Smem::TOTAL, st, (const float*)p.us,
+                         (const float*)p.vs, (const f16_t*)p.w2x, b2, w3, b3, (const F16Scales*)p.f16sc, b_rows, b, (int)h1,
+                         (int)h2, scores_out, bitsP, bitsN, xcd_natural());
+    }
+    MI_LAUNCH_CHECK("concat_fwd_f16x3_kernel");
+    rc = MI_OK;
+  } else if (precision == MI_PREC_F16) {
     // absmax of U, V, W2, w3 -> power-of-two scales (device side) -> fp16 operand copies -> the packed-generation kernel
     const hipError_t e0 = hipMemsetAsync(p.f16sc, 0, sizeof(F16Scales), st);
     if (e0 != hipSuccess) return hip_fail(e0, "hipMemsetAsync(fp16 scales)");
@@ -448,6 +499,10 @@ int mi_concat_mlp_bwd(const float* x, const float* y, const float* w1, const flo
     return MI_EWORKSPACE;
   }
   hipStream_t st = (hipStream_t)stream;
+  if (precision == MI_PREC_F16X3)
+    return concat_bwd_impl<f16_t, true>(x, y, w1, w2, b2, w3, sid_rows, sid_cols, b_rows, b, row_offset, d_img, d_txt,
+                                        (int)h1, (int)h2, stats, grad_out, scores, grad_x, grad_y, grad_w1, grad_b1, grad_w2,
+                                        grad_b2, grad_w3, grad_b3, p, st);
   if (precision == MI_PREC_F16)
     return concat_bwd_impl<f16_t>(x, y, w1, w2, b2, w3, sid_rows, sid_cols, b_rows, b, row_offset, d_img, d_txt,
                                   (int)h1, (int)h2, stats, grad_out, scores, grad_x, grad_y, grad_w1, grad_b1, grad_w2,

@@ -51,7 +51,11 @@ typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 struct F16Scales {
   unsigned amax_bits[4];  // bit patterns of max|U|, max|V|, max|W2|, max|w3| (non-negative floats order as unsigned)
 };
-constexpr float kF16GScale = 4096.0f;  // s_g: |g| <= 1 for grad_out = 1; grad_out is applied to the finished sums
+// s_g: the scale of g in the dW2 kernel's generated operand g' relu(u + v).  A power of two derived from the statistics so
+// that the LARGEST |g| of the batch -- max(exp(neg_max - lse), 1 / n_pos), grad_out left out: it is applied to the finished
+// sums -- lands in [2^lo_exp, 2^(lo_exp + 1)).  (A fixed 2^12 put the products of a 16.8 M-pair batch, g ~ 6e-8, into the
+// fp16 subnormals.)  Every kernel derives it from the same statistics block with this function.
+__device__ __forceinline__ float f16_g_scale(const mi_stats* st, int lo_exp);
 // 2^e with 2^e * a in [2^lo_exp, 2^(lo_exp + 1)) for finite a > 0; 1 otherwise.  A pure function of the bits: every
 // kernel derives the same scale from the same absmax slots.
 __device__ __forceinline__ float f16_pow2_scale(float a, int lo_exp) {
@@ -62,6 +66,7 @@ __device__ __forceinline__ float f16_pow2_scale(float a, int lo_exp) {
 }
 struct F16ScaleSet {
   float s_uv, s_w, s_ww;
+  float s_uv3;  // two-part mode (MI_PREC_F16X3): no clamp trick there, U + V sits high in the fp16 range
 };
 __device__ __forceinline__ F16ScaleSet f16_scales(const F16Scales* sc) {
   const float au = __uint_as_float(sc->amax_bits[0]), av = __uint_as_float(sc->amax_bits[1]);
@@ -70,8 +75,16 @@ __device__ __forceinline__ F16ScaleSet f16_scales(const F16Scales* sc) {
   r.s_uv = f16_pow2_scale(au + av, -2);  // (max|U| + max|V|) s in [1/4, 1/2): the clamp at 1 is never reached
   r.s_w = f16_pow2_scale(aw, 13);
   r.s_ww = f16_pow2_scale(aw * a3, 13);
+  r.s_uv3 = f16_pow2_scale(au + av, 13);
   return r;
 }
+__device__ __forceinline__ float f16_g_scale(const mi_stats* st, int lo_exp) {
+  const float gneg = expf(st->neg_max - st->lse);  // neg_max = -inf (no negatives): 0
+  const float gpos = 1.0f / (float)st->n_pos;
+  return f16_pow2_scale(fmaxf(gneg, gpos), lo_exp);
+}
+// fp16 mode: g' h <= 2^14 / 2; two-part mode: h < 2^14, so g' < 2 keeps g' h below the fp16 maximum
+constexpr int kF16GLo = 13, kF16X3GLo = 0;
 // 16-bit operand traits of the bit-expanding kernels
 template <typename OpT>
 struct Op16 {
@@ -340,7 +353,10 @@ __global__ __launch_bounds__(512) void concat_bwd_duv_kernel(
 constexpr int kDw2IB = 128;  // image rows per g batch
 
 // D slab [n_split][H2][H1]; workgroup = (k block of 256, n block of 256, pair split); wave (wn, wk): 128 n x 64 k.
-template <typename OpT>
+// X3 (OpT = f16_t; MI_PREC_F16X3): U, V are the scaled copies Us, Vs; the generated operand g' relu(u + v) is formed in
+// fp32 and split into two fp16 parts, two MFMAs per product (the bit operand {0, 2} is exact); grad_out is applied by the
+// finishing kernel (the slabs hold 2 s_uv s_g D, as in the fp16 mode).
+template <typename OpT, bool X3 = false>
 __global__ __launch_bounds__(512) void concat_bwd_dw2_kernel(
     const float* __restrict__ U, const float* __restrict__ V, const unsigned* __restrict__ bitsN,
     const float* __restrict__ S, const int64_t* __restrict__ sid_rows, const int64_t* __restrict__ sid_cols,
@@ -351,7 +367,8 @@ __global__ __launch_bounds__(512) void concat_bwd_dw2_kernel(
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   float* vt = reinterpret_cast<float*>(smem_raw);                       // [256 k][LDV]
   float* gs = vt + 256 * LDV;                                           // [kDw2IB][32]
-  bf16x8* lut = reinterpret_cast<bf16x8*>(gs + kDw2IB * 32);            // [256]
+  using LutVec = typename Op16<OpT>::Vec8;
+  LutVec* lut = reinterpret_cast<LutVec*>(gs + kDw2IB * 32);            // [256]
 
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int wn = wave >> 2, wk = wave & 3;
@@ -367,16 +384,16 @@ __global__ __launch_bounds__(512) void concat_bwd_dw2_kernel(
   if (ihi > b_rows) ihi = b_rows;
   const int64_t JB = (b + 31) / 32;
 
-  const float go = grad_out ? grad_out[0] : 1.0f;
+  const float go = X3 ? 1.0f : (grad_out ? grad_out[0] : 1.0f);
   const float lse = stats->lse;
   const float gpos = -go / (float)stats->n_pos;
-  const float gscale = kBf16 ? 0.5f : 1.0f;
+  const float gscale = X3 ? f16_g_scale(stats, kF16X3GLo) : (kBf16 ? 0.5f : 1.0f);
 
   if constexpr (kBf16) {
     if (tid < 256) {
-      bf16x8 f;
+      LutVec f;
 #pragma unroll
-      for (int q = 0; q < 8; ++q) f[q] = (bf16_t)(((tid >> q) & 1) ? 2.0f : 0.0f);
+      for (int q = 0; q < 8; ++q) f[q] = (OpT)(((tid >> q) & 1) ? 2.0f : 0.0f);
       lut[tid] = f;
     }
   }
@@ -453,7 +470,28 @@ __global__ __launch_bounds__(512) void concat_bwd_dw2_kernel(
           }
           const f32x4 g0 = *reinterpret_cast<const f32x4*>(&gs[il * 32 + 16 * s + 8 * h]);
           const f32x4 g1 = *reinterpret_cast<const f32x4*>(&gs[il * 32 + 16 * s + 8 * h + 4]);
-          if constexpr (kBf16) {
+          if constexpr (X3) {
+            f16x8 ph[2], pl[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+#pragma unroll
+              for (int q = 0; q < 8; ++q) {
+                const float pv = fmaxf(ucur[t] + vreg[t][q], 0.0f) * (q < 4 ? g0[q] : g1[q - 4]);
+                const f16_t hi = (f16_t)pv;
+                ph[t][q] = hi;
+                pl[t][q] = (f16_t)(pv - (float)hi);
+              }
+            }
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+              const f16x8 mf = lut[(wcur[a] >> (16 * s + 8 * h)) & 0xFFu];
+#pragma unroll
+              for (int t = 0; t < 2; ++t) {
+                acc[a][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(mf, pl[t], acc[a][t], 0, 0, 0);
+                acc[a][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(mf, ph[t], acc[a][t], 0, 0, 0);
+              }
+            }
+          } else if constexpr (kBf16) {
             bf16x8 hf[2];
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
@@ -576,13 +614,19 @@ __global__ __launch_bounds__(256) void concat_bwd_finish_w2_kernel(const float* 
                                                                    float* __restrict__ dW2, float* __restrict__ dW3,
                                                                    float* __restrict__ db2, float* __restrict__ db3,
                                                                    const F16Scales* __restrict__ sc = nullptr,
-                                                                   const float* __restrict__ grad_out = nullptr) {
+                                                                   const float* __restrict__ grad_out = nullptr,
+                                                                   const mi_stats* __restrict__ stats = nullptr,
+                                                                   int x3 = 0) {
   __shared__ float red[4];
   const int n = blockIdx.x, tid = threadIdx.x;
   const float w3n = w3[n];
   // fp16 mode: the slabs hold 2 s_uv s_g D computed for grad_out = 1 (mi_concat_f16.h)
   float dscale = 1.0f;
-  if (sc) dscale = (grad_out ? grad_out[0] : 1.0f) / (2.0f * kF16GScale * f16_scales(sc).s_uv);
+  if (sc) {
+    const F16ScaleSet ss = f16_scales(sc);
+    dscale = (grad_out ? grad_out[0] : 1.0f) /
+             (2.0f * f16_g_scale(stats, x3 ? kF16X3GLo : kF16GLo) * (x3 ? ss.s_uv3 : ss.s_uv));
+  }
   float dot = 0.0f;
   for (int k = tid; k < H1; k += 256) {
     float d = 0.0f;

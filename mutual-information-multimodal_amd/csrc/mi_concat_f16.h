@@ -16,7 +16,8 @@
 //     s_uv : (max|U| + max|V|) s_uv in (1/4, 1/2]            -> Uh = fp16(U s_uv), Vh = fp16(V s_uv)
 //     s_w  : max|W2| s_w in [2^13, 2^14)                      -> W2h = fp16(W2 s_w)
 //     s_ww : max|w3| max|W2| s_ww in [2^13, 2^14) (a bound)   -> W2wP = fp16(w3[n] W2[n, k] s_ww)  (dU / dV kernel)
-//     s_g  : 2^12 (|g| <= 1 for grad_out = 1; grad_out is applied to the finished sums)
+//     s_g  : max|g| s_g in [2^13, 2^14), max|g| from the statistics block (f16_g_scale); grad_out is applied to the
+//            finished sums
 // Scales are powers of two: scaling is exact, the only roundings are the conversions to fp16 and the packed operations
 // (each correctly rounded).  Sums are accumulated in fp32 by the MFMA; the scale factors are undone once, in fp32, in the
 // epilogues.  Values below 2^-14 after scaling become fp16 subnormals (absolute error 2^-25 of the tensor's largest
@@ -120,6 +121,22 @@ static __global__ void f16_prep_w2w_kernel(const float* __restrict__ w2, const f
     const int k = (int)(e / H2), m = (int)(e % H2);
     const int n = slot_to_n(m);
     out[e] = (f16_t)(w2[(int64_t)n * H1 + k] * w3[n] * sww);
+  }
+}
+
+// two-part form for MI_PREC_F16X3: out [2][H1][H2] (hi, lo)
+static __global__ void f16x3_prep_w2w_kernel(const float* __restrict__ w2, const float* __restrict__ w3, int H1, int H2,
+                                             const F16Scales* __restrict__ sc, f16_t* __restrict__ out) {
+  const float sww = f16_scales(sc).s_ww;
+  const int64_t total = (int64_t)H1 * H2;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+    const int k = (int)(e / H2), m = (int)(e % H2);
+    const int n = slot_to_n(m);
+    const float v = w2[(int64_t)n * H1 + k] * w3[n] * sww;
+    const f16_t hi = (f16_t)v;
+    out[e] = hi;
+    out[total + e] = (f16_t)(v - (float)hi);
   }
 }
 
@@ -306,6 +323,200 @@ __global__ __launch_bounds__(256, 2) void concat_fwd_f16_kernel(
   }
 }
 
+// ================================================================================================= forward, two-part fp16
+// MI_PREC_F16X3: the fp32-tolerance mode of this critic at a third of the fp16 rate (the exact fp32-input MFMA runs at a
+// sixteenth).  Every operand of the big product is TWO fp16 parts, hi = fp16(v), lo = fp16(v - hi) (22 significant bits
+// under the same power-of-two scales as the fp16 mode), and a product is hi*hi + hi*lo + lo*hi on three MFMAs with fp32
+// accumulation (the lo*lo term is below 2^-22).  Same tiling, LDS layout and DMA as concat_fwd_f16_kernel with a 32-deep k
+// tile: a W2 tile row is [hi 32 k | lo 32 k] (128 bytes, from the interleaved copy W2x), the V / U tile rows are 32 fp32
+// values (128 bytes) of the pre-scaled copies Us = U s_uv, Vs = V s_uv -- relu(u + v) is formed in fp32 and split in
+// registers (two conversions, one subtraction per pair of elements).
+__global__ __launch_bounds__(256, 2) void concat_fwd_f16x3_kernel(
+    const float* __restrict__ Us, const float* __restrict__ Vs, const f16_t* __restrict__ W2x /* [H2][H1 / 32][hi 32 | lo 32] */,
+    const float* __restrict__ b2, const float* __restrict__ w3, const float* __restrict__ b3,
+    const F16Scales* __restrict__ sc, int64_t b_rows, int64_t b, int H1, int H2, float* __restrict__ S,
+    unsigned long long* __restrict__ bitsP, unsigned* __restrict__ bitsN, int natural_order) {
+  using L = FwdF16Smem;
+  constexpr int NP = L::NP;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* b2s = reinterpret_cast<float*>(smem + 2 * L::BUF_BYTES);
+  float* w3s = b2s + NP;
+  float* sred = w3s + NP;  // [256]
+
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int wp = wave;
+  const int c = lane & 31, h = lane >> 5;
+  const BitTransposeLane btl = bit_transpose_lane(c);
+  const int n_jt = (int)((b + kFwdTJ - 1) / kFwdTJ), n_it = (int)((b_rows + kFwdTI - 1) / kFwdTI);
+  const int njx = (n_jt + 7) / 8;
+  int jt = (int)(blockIdx.x & 7) + 8 * (int)((blockIdx.x >> 3) / n_it);
+  int it = (int)((blockIdx.x >> 3) % n_it);
+  if (natural_order) {
+    jt = (int)(blockIdx.x % (8 * njx));
+    it = (int)(blockIdx.x / (8 * njx));
+  }
+  if (jt >= n_jt || it >= n_it) return;
+  const int64_t i0 = (int64_t)it * kFwdTI, j0 = (int64_t)jt * kFwdTJ;
+  const int n_pass = H2 / NP;
+  const int n_kt = H1 / 32;
+  const int64_t JB = (b + 31) / 32;
+  const F16ScaleSet scl = f16_scales(sc);
+  const float s_in = scl.s_uv3 * scl.s_w, inv_in = 1.0f / s_in;
+
+  // ---- DMA source addresses: every instruction moves 8 rows x 128 B (rows of W2x, Vs, Us are H1 * 4 bytes long) -----------
+  int woff[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int row = 32 * wave + 8 * q + (lane >> 3);
+    woff[q] = row * H1 * 4 + (((lane & 7) ^ ((row >> 1) & 7)) << 4);
+  }
+  const char* vsrc;
+  {
+    const int row = 8 * wave + (lane >> 3);
+    int64_t gj = j0 + row;
+    if (gj >= b) gj = b - 1;
+    vsrc = reinterpret_cast<const char*>(Vs + gj * H1) + (((lane & 7) ^ ((row >> 1) & 7)) << 4);
+  }
+  const char* usrc;
+  {
+    int64_t li = i0 + (lane >> 3);
+    if (li >= b_rows) li = b_rows - 1;
+    usrc = reinterpret_cast<const char*>(Us + li * H1) + ((lane & 7) << 4);
+  }
+  auto issue_tile = [&](int pass, int kt, int buf) {
+    char* base = smem + buf * L::BUF_BYTES;
+    const char* wsrc = reinterpret_cast<const char*>(W2x) + ((int64_t)pass * NP) * H1 * 4 + kt * 128;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) MI_GLDS16(wsrc + woff[q], base + (32 * wave + 8 * q) * 128);
+    MI_GLDS16(vsrc + kt * 128, base + L::W_BYTES + (8 * wave) * 128);
+    if (wave == 0) MI_GLDS16(usrc + kt * 128, base + L::W_BYTES + L::V_BYTES);
+  };
+
+  const int wrow_off = c * 128;
+  const int wswz = (c >> 1) & 7;
+  const int vrow_off = L::W_BYTES + c * 128;
+  const int urow_off = L::W_BYTES + L::V_BYTES + (2 * wp) * 128;
+
+  if (tid < NP) b2s[tid] = 0.0f;
+  float s_total[2] = {0.0f, 0.0f};
+
+  for (int pass = 0; pass < n_pass; ++pass) {
+    __syncthreads();
+    if (tid < NP) {
+      b2s[tid] = b2[pass * NP + tid] * s_in;
+      w3s[tid] = w3[pass * NP + tid] * inv_in;
+    }
+    issue_tile(pass, 0, 0);
+    __syncthreads();
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float bias = b2s[a * 32 + (r & 3) + 8 * (r >> 2) + 4 * h];
+        acc[a][0][r] = bias;
+        acc[a][1][r] = bias;
+      }
+
+    for (int kt = 0; kt < n_kt; ++kt) {
+      const int buf = kt & 1;
+      if (kt + 1 < n_kt) issue_tile(pass, kt + 1, buf ^ 1);
+      const char* base = smem + buf * L::BUF_BYTES;
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        f16x8 wh[4], wl[4];
+        const int hpos = ((2 * kk + h) ^ wswz) << 4, lpos = ((4 + 2 * kk + h) ^ wswz) << 4;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+          wh[a] = *reinterpret_cast<const f16x8*>(base + wrow_off + a * 32 * 128 + hpos);
+          wl[a] = *reinterpret_cast<const f16x8*>(base + wrow_off + a * 32 * 128 + lpos);
+        }
+        // this lane's 8 k values: 16 kk + 8 h .. + 7 = 16-byte chunks 4 kk + 2 h and 4 kk + 2 h + 1 of the fp32 rows
+        const int q0 = 4 * kk + 2 * h;
+        const f32x4 v0 = *reinterpret_cast<const f32x4*>(base + vrow_off + ((q0 ^ wswz) << 4));
+        const f32x4 v1 = *reinterpret_cast<const f32x4*>(base + vrow_off + (((q0 + 1) ^ wswz) << 4));
+        f16x8 hh[2], hl[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const f32x4 u0 = *reinterpret_cast<const f32x4*>(base + urow_off + t * 128 + q0 * 16);
+          const f32x4 u1 = *reinterpret_cast<const f32x4*>(base + urow_off + t * 128 + q0 * 16 + 16);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float x0 = fmaxf(u0[e] + v0[e], 0.0f), x1 = fmaxf(u1[e] + v1[e], 0.0f);
+            const f16_t h0 = (f16_t)x0, h1 = (f16_t)x1;
+            hh[t][e] = h0;
+            hh[t][4 + e] = h1;
+            hl[t][e] = (f16_t)(x0 - (float)h0);
+            hl[t][4 + e] = (f16_t)(x1 - (float)h1);
+          }
+        }
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+          for (int t = 0; t < 2; ++t) {
+            acc[a][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[a], hh[t], acc[a][t], 0, 0, 0);  // small terms first
+            acc[a][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[a], hl[t], acc[a][t], 0, 0, 0);
+            acc[a][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[a], hh[t], acc[a][t], 0, 0, 0);
+          }
+      }
+      __syncthreads();
+    }
+
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int64_t li = i0 + 2 * wp + t;
+      const int64_t gj = j0 + c;
+      const bool row_ok = li < b_rows, col_ok = gj < b;
+      const int64_t lic = row_ok ? li : 0, gjc = col_ok ? gj : 0;
+      s_total[t] += fwd_epilogue_row(acc[0][t], acc[1][t], acc[2][t], acc[3][t], w3s, h, c, bitsP != nullptr, row_ok,
+                                     col_ok, bitsP + bitsp_index(lic, gjc, h, pass, (b + 31) / 32, (int)(H2 / 128)),
+                                     bitsN + (lic * JB + jt) * H2 + pass * 128, btl);
+    }
+  }
+
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const float s = s_total[t] + __shfl_xor(s_total[t], 32);
+    if (h == 0) sred[(2 * wp + t) * 32 + c] = s;
+  }
+  __syncthreads();
+  {
+    const int il = tid >> 5, jl = tid & 31;
+    const int64_t li = i0 + il, gj = j0 + jl;
+    if (li < b_rows && gj < b) S[li * b + gj] = sred[tid] + b3[0];
+  }
+}
+
+// Us = U s_uv3, Vs = V s_uv3 (fp32, exact; s_uv3 puts max|U| + max|V| in [2^13, 2^14): no clamp trick in this mode), W2x[n][kt][hi 32 | lo 32] (two-part fp16 of W2 s_w); when the backward will run
+// also VsT [H1][b] (fp32 transpose of Vs: the dW2 kernel stages [k][column] tiles).
+struct F16X3PrepArgs {
+  const float *u, *v, *w2;
+  int64_t b_rows, b;
+  int h1, h2;
+  const F16Scales* sc;
+  float *us, *vs;
+  f16_t* w2x;
+};
+static __global__ __launch_bounds__(256) void f16x3_prep_kernel(F16X3PrepArgs A) {
+  const F16ScaleSet s = f16_scales(A.sc);
+  const int64_t nu = A.b_rows * A.h1, nv = A.b * A.h1, nw = (int64_t)A.h2 * A.h1;
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < nu; e += stride) A.us[e] = A.u[e] * s.s_uv3;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < nv; e += stride) A.vs[e] = A.v[e] * s.s_uv3;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < nw; e += stride) {
+    const int64_t n = e / A.h1;
+    const int k = (int)(e % A.h1);
+    const float w = A.w2[e] * s.s_w;
+    const f16_t hi = (f16_t)w;
+    const f16_t lo = (f16_t)(w - (float)hi);
+    f16_t* row = A.w2x + n * (2 * (int64_t)A.h1) + (k >> 5) * 64 + (k & 31);
+    row[0] = hi;
+    row[32] = lo;
+  }
+}
+
 // ================================================================================================= dW2 kernel
 // D[n, k] = sum_p M[p, n] fp16(g'_p h_pk),  g' = fp16(g s_g) (grad_out NOT included), h_pk = clamp(Uh_i[k] + Vh_j[k]).
 // Same decomposition as concat_bwd_dw2_kernel: workgroup = (k block of 256, n block of 256, row split), wave (wn, wk):
@@ -349,6 +560,7 @@ __global__ __launch_bounds__(512) void concat_bwd_dw2_f16_kernel(
 
   const float lse = stats->lse;
   const float gpos = -1.0f / (float)stats->n_pos;
+  const float gscale = f16_g_scale(stats, kF16GLo);
 
   if (tid < 256) {
     f16x8 f;
@@ -401,7 +613,7 @@ __global__ __launch_bounds__(512) void concat_bwd_dw2_f16_kernel(
         const int64_t li = ib + il, gj = j0 + jl;
         float g = 0.0f;
         if (li < ihi && gj < b)
-          g = kF16GScale * pair_grad(S[li * b + gj], row_offset + li, gj, sid_rows[li], sid_cols[gj], lse, 1.0f, gpos);
+          g = gscale * pair_grad(S[li * b + gj], row_offset + li, gj, sid_rows[li], sid_cols[gj], lse, 1.0f, gpos);
         gs[e] = (f16_t)g;
       }
       __syncthreads();
@@ -512,11 +724,15 @@ struct Duv3Smem {
   static constexpr int LUT_BYTES = 256 * 16;
   static constexpr int DVRED_BYTES = 4 * 4 * KC * 4;  // [wave][4 columns][KC] fp32
   static constexpr int GSW_BYTES = 4 * 64 * 4;        // [wave][64 pairs] fp32
-  static size_t total(int h2) { return (size_t)KC * h2 * 2 + LUT_BYTES + DVRED_BYTES + GSW_BYTES; }
+  static size_t total(int h2, bool x3 = false) {
+    return (size_t)KC * h2 * 2 * (x3 ? 2 : 1) + LUT_BYTES + DVRED_BYTES + GSW_BYTES;
+  }
 };
 constexpr int kDuv3TJ = 4;  // text columns per step
 
-template <typename OpT, typename UvT>
+// X3 (MI_PREC_F16X3): W2wP holds TWO parts per element, [2][H1][H2] (hi, lo); the slice of both sits in LDS (one workgroup
+// per CU then) and every product is two MFMAs (the bit operand is exact).
+template <typename OpT, typename UvT, bool X3 = false>
 __global__ __launch_bounds__(256, 2) void concat_bwd_duv3_kernel(
     const UvT* __restrict__ U, const UvT* __restrict__ V, const OpT* __restrict__ W2wP,
     const unsigned long long* __restrict__ bitsP, const float* __restrict__ S, const int64_t* __restrict__ sid_rows,
@@ -527,8 +743,9 @@ __global__ __launch_bounds__(256, 2) void concat_bwd_duv3_kernel(
   using Vec8 = typename Op16<OpT>::Vec8;
   constexpr int KC = Duv3Smem::KC, NT = 2;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  char* wt = smem_raw;                                                       // [KC][H2] 16-bit, swizzled
-  const int wt_bytes = KC * H2 * 2;
+  char* wt = smem_raw;                                                       // [KC][H2] 16-bit, swizzled (X3: hi, then lo)
+  const int wt_part = KC * H2 * 2;
+  const int wt_bytes = X3 ? 2 * wt_part : wt_part;
   Vec8* lut = reinterpret_cast<Vec8*>(smem_raw + wt_bytes);                  // [256]
   float* dvred = reinterpret_cast<float*>(smem_raw + wt_bytes + Duv3Smem::LUT_BYTES);  // [4][4][KC]
   float* gsw = dvred + 4 * 4 * KC;                                           // [4][64]
@@ -562,6 +779,11 @@ __global__ __launch_bounds__(256, 2) void concat_bwd_duv3_kernel(
       u32x4 x = {0u, 0u, 0u, 0u};
       if (kc0 + row < H1) x = *reinterpret_cast<const u32x4*>(W2wP + (int64_t)(kc0 + row) * H2 + 8 * q);
       *reinterpret_cast<u32x4*>(wt + row * (H2 * 2) + ((q ^ (row & 15)) << 4)) = x;
+      if constexpr (X3) {
+        u32x4 xl = {0u, 0u, 0u, 0u};
+        if (kc0 + row < H1) xl = *reinterpret_cast<const u32x4*>(W2wP + (int64_t)H1 * H2 + (int64_t)(kc0 + row) * H2 + 8 * q);
+        *reinterpret_cast<u32x4*>(wt + wt_part + row * (H2 * 2) + ((q ^ (row & 15)) << 4)) = xl;
+      }
     }
     {
       Vec8 f;
@@ -672,6 +894,11 @@ __global__ __launch_bounds__(256, 2) void concat_bwd_duv3_kernel(
           for (int ct = 0; ct < NT; ++ct) {
             // row 32 ct + c: (row & 15) == (c & 15)
             const Vec8 bfr = *reinterpret_cast<const Vec8*>(wt + brow_off + ct * 32 * (H2 * 2) + ((q ^ (c & 15)) << 4));
+            if constexpr (X3) {
+              const Vec8 bfl = *reinterpret_cast<const Vec8*>(wt + wt_part + brow_off + ct * 32 * (H2 * 2) + ((q ^ (c & 15)) << 4));
+#pragma unroll
+              for (int m = 0; m < 2; ++m) acc[m][ct] = mfma16(af[m], bfl, acc[m][ct]);
+            }
 #pragma unroll
             for (int m = 0; m < 2; ++m) acc[m][ct] = mfma16(af[m], bfr, acc[m][ct]);
           }

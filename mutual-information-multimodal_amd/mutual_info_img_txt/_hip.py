@@ -21,7 +21,7 @@ MI_PREC_F32, MI_PREC_BF16, MI_PREC_BF16X3, MI_PREC_FP8, MI_PREC_F16, MI_PREC_F16
 ESTIMATORS = {"dv": MI_DV, "infonce": MI_INFONCE}
 PRECISIONS = {"f32": MI_PREC_F32, "fp32": MI_PREC_F32, "float32": MI_PREC_F32, "f32_exact": MI_PREC_F32,
               "bf16": MI_PREC_BF16, "bfloat16": MI_PREC_BF16, "bf16x3": MI_PREC_BF16X3, "fp8": MI_PREC_FP8,
-              "f16": MI_PREC_F16, "fp16": MI_PREC_F16, "float16": MI_PREC_F16}
+              "f16": MI_PREC_F16, "fp16": MI_PREC_F16, "float16": MI_PREC_F16, "f16x3": MI_PREC_F16X3}
 # names that ask for "fp32 results" without insisting on exact fp32 products (see resolve_precision)
 F32_NAMES = ("f32", "fp32", "float32")
 
@@ -64,6 +64,7 @@ SIGNATURES = {
     "mi_bilinear_bwd": (c_int, [_P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I, _P, _P, _P, _P, _P, _P, _SZ, _I, _P]),
     "mi_bilinear_raw_records": (_SZ, [_I64, _I64, _I64, _I64, _I, _P]),
     "mi_bilinear_bwd_records": (c_int, [_P] * 5 + [_I64] * 5 + [_I, _I, _P, _I64, _I64] + [_P] * 7 + [_SZ, _P]),
+    "mi_bilinear_bwd_dw": (c_int, [_I64, _I64, _I64, _I64, _I, _P, _P, _SZ, _P]),
     "mi_bilinear_prep_local": (c_int, [_P, _P, _I64, _I64, _I64, _I64, _I, _P, _SZ, _P]),
     "mi_bilinear_fp8_stage": (c_int, [_P, _P, _P, _I64, _I64, _I64, _I64, _I, _P, _P, _SZ, _P]),
     "mi_bilinear_step": (c_int, [_P, _P, _P, _P, _I64, _I64, _I64, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _SZ, _P]),
@@ -71,6 +72,7 @@ SIGNATURES = {
     "mi_bilinear_path": (c_int, [_I64, _I64, _I64, _I64, _I]),
     "mi_separable_path": (c_int, [_I64, _I64, _I64, _I64, _I64, _I]),
     "mi_separable_workspace_bytes": (_SZ, [_I64, _I64, _I64, _I64, _I64, _I]),
+    "mi_separable_step": (c_int, [_P] * 5 + [_I64] * 4 + [_I, _I] + [_P] * 9 + [_SZ, _P]),
     "mi_separable_fwd": (c_int, [_P] * 6 + [_I64] * 6 + [_I, _I, _I] + [_P] * 4 + [_SZ, _P]),
     "mi_separable_bwd": (c_int, [_P] * 6 + [_I64] * 6 + [_I] + [_P] * 7 + [_SZ, _I, _P]),
     "mi_concat_mlp_workspace_bytes": (_SZ, [_I64, _I64, _I64, _I64, _I64, _I64, _I, _I]),

@@ -149,6 +149,34 @@ class HipBilinearOps:
                   gy.data_ptr(), gw.data_ptr(), ws.data_ptr(), ws.numel())
         return loss, stats, gx, gy, [gw]
 
+    def merge_backward_tail(self, saved, records_all, n_pos, estimator, grad_out, out=None):
+        """The first launch of merge_backward only (mi_bilinear_bwd_records with grad_w = NULL): statistics, loss, grad_x and
+        the partial grad_y.  The caller starts the reduce-scatter of grad_y and then calls ``backward_dw``."""
+        x, y_all, w, sid_rows, sid_all, row_offset, precision, ws = saved
+        br, dx = x.shape
+        b, dy = y_all.shape
+        dev = x.device
+        if out is None:
+            gx, gy = torch.empty_like(x), torch.empty_like(y_all)
+        else:
+            gx, gy, _ = out
+        stats = _hip.new_stats(dev)
+        loss = torch.empty(1, dtype=torch.float32, device=dev)
+        _hip.call("mi_bilinear_bwd_records", dev, x.data_ptr(), y_all.data_ptr(), w.data_ptr(), sid_rows.data_ptr(),
+                  sid_all.data_ptr(), br, b, row_offset, dx, dy, precision, estimator, records_all.data_ptr(),
+                  records_all.shape[0], n_pos, grad_out.data_ptr(), loss.data_ptr(), stats.data_ptr(), gx.data_ptr(),
+                  gy.data_ptr(), None, ws.data_ptr(), ws.numel())
+        return loss, stats, gx, gy
+
+    def backward_dw(self, saved, out=None):
+        """dW = X^T dT (mi_bilinear_bwd_dw) from the workspace merge_backward_tail left."""
+        x, y_all, w, _sr, _sa, _ro, precision, ws = saved
+        br, dx = x.shape
+        b, dy = y_all.shape
+        gw = torch.empty_like(w) if out is None else out[2][0]
+        _hip.call("mi_bilinear_bwd_dw", x.device, br, b, dx, dy, precision, gw.data_ptr(), ws.data_ptr(), ws.numel())
+        return [gw]
+
     def merge(self, records, n_pos, estimator):
         lib = _hip.load()
         dev = records.device
@@ -293,6 +321,29 @@ def _reduce_scatter_rows(t: torch.Tensor, group) -> torch.Tensor:
     out = torch.empty((rows,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
     dist.reduce_scatter_tensor(out, t.contiguous(), group=group)
     return out
+
+
+def _reduce_scatter_rows_start(t: torch.Tensor, group):
+    """Start the reduce-scatter of t [G*r, ...] (async: on the backend's own stream); returns a function that waits for it
+    and returns this rank's block.  What the caller launches in between runs beside the collective."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    rows = t.shape[0] // world
+    t = t.contiguous()
+    if dist.get_backend(group) == "gloo":  # gloo has no reduce_scatter: all-reduce and slice (CPU tests only)
+        work = dist.all_reduce(t, group=group, async_op=True)
+
+        def finish():
+            work.wait()
+            return t[rank * rows:(rank + 1) * rows].clone()
+        return finish
+    out = torch.empty((rows,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+    work = dist.reduce_scatter_tensor(out, t, group=group, async_op=True)
+
+    def finish():
+        work.wait()
+        return out
+    return finish
 
 
 def fp8_global_scales(ops, x, y_all, params, group) -> None:
@@ -630,6 +681,24 @@ class GlobalBatchGraphStep:
         self._gather_inputs()
         self._forward()
         self._gather_records()
+        if self._raw and hasattr(self.ops, "merge_backward_tail") and not os.environ.get("MI_DIST_NO_RS_OVERLAP"):
+            # the reduce-scatter of dY needs the backward's FIRST launch only: started (on the backend's stream) before the
+            # dW launch, it runs beside it; the parameter all-reduce follows dW.  Same five collectives, same order on
+            # every rank.  (MI_DIST_NO_RS_OVERLAP=1: A/B switch.)
+            got = self.ops.merge_backward_tail(self.saved, self.records_raw, self.world * self.x.shape[0], self.est,
+                                               self.grad_out, out=self._out)
+            self.loss, self.stats = got[0], got[1]
+            if self._out is None:
+                self.grad_x, self.grad_y_partial = got[2], got[3]
+            finish = _reduce_scatter_rows_start(self.grad_y_partial, self.group)
+            gp = self.ops.backward_dw(self.saved, out=self._out)
+            if self._out is None:
+                for v, g in zip(self.grad_params, gp):
+                    v.copy_(g)
+            if self.grad_flat is not None:
+                dist.all_reduce(self.grad_flat, group=self.group)
+            self.grad_y = finish()
+            return self.loss
         self._merge_backward()
         self._exchange_gradients()
         return self.loss

@@ -170,6 +170,11 @@ class GraphedMiStep:
                       self.sid.data_ptr(), self.b, self.dx, self.dy, self.est, self.prec, self.grad_out.data_ptr(),
                       self.loss_buf.data_ptr(), self.stats.data_ptr(), self.record.data_ptr(), self.grad_x.data_ptr(),
                       self.grad_y.data_ptr(), g[0].data_ptr() if g else None, self.ws.data_ptr(), self.ws.numel())
+        elif self.kind == "separable":
+            _hip.call("mi_separable_step", self.device, self.x.data_ptr(), self.y.data_ptr(), p[0].data_ptr(), p[1].data_ptr(),
+                      self.sid.data_ptr(), self.b, self.dx, self.dy, self.k, self.est, self.prec, self.grad_out.data_ptr(),
+                      self.loss_buf.data_ptr(), self.stats.data_ptr(), self.record.data_ptr(), self.grad_x.data_ptr(),
+                      self.grad_y.data_ptr(), g[0].data_ptr(), g[1].data_ptr(), self.ws.data_ptr(), self.ws.numel())
         else:
             self._fwd()
             self._bwd()

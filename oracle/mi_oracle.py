@@ -373,7 +373,24 @@ def _concat_matrix_step_blocked(x, y, study_id, params, estimator, rb, round_fn=
     return {"scores": s_all, "loss": loss, "dx": xl.grad, "dy": yl.grad, "dparams": [p.grad for p in pl]}
 
 
-def concat_step_rounded(x, y, study_id, params, estimator: str, row_block: int = 64, round_fn=None):
+def _scores_pass(block_scores, b, row_block, r0, r1, scores_outside, progress, dtype):
+    """[B, B] scores by row blocks; rows outside [r0, r1) from ``scores_outside`` when given."""
+    if scores_outside is None:
+        lo, hi = 0, b
+        s_all = torch.empty(b, b, dtype=dtype)
+    else:
+        lo, hi = r0, r1
+        s_all = scores_outside.to(dtype).clone()
+    for s in range(lo, hi, row_block):
+        e = min(s + row_block, hi)
+        s_all[s:e] = block_scores(s)[:e - s]
+        if progress is not None and ((s - lo) // row_block) % 16 == 0:
+            progress(f"oracle scores: row {s} of [{lo}, {hi})")
+    return s_all
+
+
+def concat_step_rounded(x, y, study_id, params, estimator: str, row_block: int = 64, round_fn=None, rows=None,
+                        progress=None, scores_outside=None):
     """fp64 forward + backward of the factorised concat-MLP critic with ALL rounding points of the 16-bit MFMA path
     (csrc/mi_concat_fwd_dma.h, csrc/mi_concat_bwd.h), the backward in closed form instead of autograd:
 
@@ -384,7 +401,12 @@ def concat_step_rounded(x, y, study_id, params, estimator: str, row_block: int =
 
     With round_fn = identity this equals ``concat_matrix_step`` (checked in tests/test_oracle_golden.py), which pins the
     closed form; with round_fn = round_bf16 (default) it is what the bf16 kernels compute up to fp32 accumulation order.
-    Rows are processed ``row_block`` at a time ([rb, B, h1] fp64 temporaries)."""
+    Rows are processed ``row_block`` at a time ([rb, B, h1] fp64 temporaries).  ``rows = (r0, r1)``: only the image rows
+    [r0, r1) contribute to the gradients (a rank's share of a sharded batch: dx rows of the block, the block's partial dy
+    and parameter gradients; scores, loss and g are those of the whole batch).  ``progress`` (optional callable) is called
+    with a short string now and then (long runs on a harness that kills silent commands).  ``scores_outside`` ([B, B],
+    with ``rows``): the scores of the rows OUTSIDE [r0, r1) are taken from it instead of being recomputed (three quarters
+    of the host time at B = 4096; the caller checks those scores elsewhere); the block's own rows are always computed."""
     rf = round_bf16 if round_fn is None else round_fn
     w1, b1, w2, b2, w3, b3 = [p.detach() for p in params]
     x, y = x.detach(), y.detach()
@@ -401,26 +423,32 @@ def concat_step_rounded(x, y, study_id, params, estimator: str, row_block: int =
         z2 = F.linear(rf(h1), w2r, b2)
         return pre, h1, z2
 
-    s_all = torch.cat([F.linear(F.relu(block(s)[2]), w3, b3).squeeze(-1) for s in range(0, b, row_block)], 0)
+    r0, r1 = (0, b) if rows is None else rows
+    s_all = _scores_pass(lambda s: F.linear(F.relu(block(s)[2]), w3, b3).squeeze(-1), b, row_block, r0, r1, scores_outside,
+                         progress, x.dtype)
     loss = bound_from_matrix(s_all, study_id, estimator)
     g = matrix_grad_scores(s_all, study_id)
     du = torch.zeros_like(u)
     dv = torch.zeros_like(v)
     dmat = torch.zeros_like(w2)
     mvec = torch.zeros_like(b2)
-    for s in range(0, b, row_block):
+    for s in range(r0, r1, row_block):
+        e = min(s + row_block, r1)
         pre, h1, z2 = block(s)
-        gb = g[s:s + row_block, :, None]
+        pre, h1, z2 = pre[:e - s], h1[:e - s], z2[:e - s]
+        gb = g[s:e, :, None]
         m = (z2 > 0).to(x.dtype)
         dh1 = gb * (pre > 0).to(x.dtype) * (m @ w2w)
-        du[s:s + row_block] = dh1.sum(1)
+        du[s:e] = dh1.sum(1)
         dv += dh1.sum(0)
         hf = rf(h1 * gb)
         dmat += torch.einsum("ijn,ijk->nk", m, hf)
         mvec += (gb * m).sum((0, 1))
+        if progress is not None and ((s - r0) // row_block) % 8 == 0:
+            progress(f"oracle gradients: row {s} of [{r0}, {r1})")
     dparams = [torch.cat([du.t() @ x, dv.t() @ y], 1), dv.sum(0), w3v[:, None] * dmat, w3v * mvec,
-               ((w2 * dmat).sum(1) + b2 * mvec).reshape(w3.shape), g.sum().reshape(b3.shape)]
-    return {"scores": s_all, "loss": loss, "dx": du @ w1[:, :dx], "dy": dv @ w1[:, dx:], "dparams": dparams}
+               ((w2 * dmat).sum(1) + b2 * mvec).reshape(w3.shape), g[r0:r1].sum().reshape(b3.shape)]
+    return {"scores": s_all, "loss": loss, "dx": (du @ w1[:, :dx])[r0:r1], "dy": dv @ w1[:, dx:], "dparams": dparams}
 
 
 def round_f16(t: torch.Tensor) -> torch.Tensor:
@@ -435,18 +463,22 @@ def f16_pow2_scale(a: float, lo_exp: int) -> float:
     return 2.0 ** (lo_exp + 1 - e)
 
 
-def concat_step_f16(x, y, study_id, params, estimator: str, row_block: int = 64):
+def concat_step_f16(x, y, study_id, params, estimator: str, row_block: int = 64, rows=None, progress=None,
+                    scores_outside=None):
     """fp64 forward + backward of the factorised concat-MLP critic with the rounding points of the library's fp16 mode
     (csrc/mi_concat_f16.h, MI_PREC_F16), the backward in closed form:
 
-      scales    s_uv, s_w, s_ww: powers of two from the absmax of U, V, W2, w3 (f16_pow2_scale); s_g = 2^12
+      scales    s_uv, s_w, s_ww: powers of two from the absmax of U, V, W2, w3 (f16_pow2_scale); s_g: the power of two that
+                puts the batch's largest |g| = max(exp(neg_max - lse), 1 / B) into [2^13, 2^14)
       forward   Uh = fp16(U s_uv), Vh = fp16(V s_uv); h = fp16(clamp(Uh_i + Vh_j, 0, 1)) (packed fp16 add with the clamp
                 modifier = relu); W2h = fp16(W2 s_w);  Z2 = (h W2h^T) / (s_uv s_w) + b2;  scores from Z2 unrounded
       dU / dV   E[p, k] = sum_n M[p, n] fp16(w3[n] W2[n, k] s_ww) / s_ww; relu' of layer 1 decided on Uh_i + Vh_j > 0
       dW2 ...   D[n, k] = sum_p M[p, n] fp16(fp16(g_p s_g) h_pk) / (s_uv s_g)
       everything else (first layer, bound, g, the finishing sums) exact.
 
-    The absmax values are taken from fp32 U, V as the library does (its first layer is an exact-fp32 GEMM)."""
+    The absmax values are taken from fp32 U, V as the library does (its first layer is an exact-fp32 GEMM).  ``rows`` /
+    ``progress`` as in ``concat_step_rounded``; with ``rows`` the scale s_uv is taken from the U rows of the block, as a
+    rank of a sharded run does."""
     w1, b1, w2, b2, w3, b3 = [p.detach() for p in params]
     x, y = x.detach(), y.detach()
     b, dx = x.shape
@@ -454,10 +486,10 @@ def concat_step_f16(x, y, study_id, params, estimator: str, row_block: int = 64)
     u = F.linear(x, w1[:, :dx])
     v = F.linear(y, w1[:, dx:], b1)
     f32max = lambda t: float(t.float().abs().max())  # noqa: E731
-    s_uv = f16_pow2_scale(float(torch.tensor(f32max(u), dtype=torch.float32) + torch.tensor(f32max(v), dtype=torch.float32)), -2)
+    r0, r1 = (0, b) if rows is None else rows
+    s_uv = f16_pow2_scale(float(torch.tensor(f32max(u[r0:r1]), dtype=torch.float32) + torch.tensor(f32max(v), dtype=torch.float32)), -2)
     s_w = f16_pow2_scale(f32max(w2), 13)
     s_ww = f16_pow2_scale(float(torch.tensor(f32max(w2), dtype=torch.float32) * torch.tensor(f32max(w3v), dtype=torch.float32)), 13)
-    s_g = 4096.0
     uh, vh = round_f16(u * s_uv), round_f16(v * s_uv)
     w2h = round_f16(w2 * s_w)
     w2w = round_f16(w2 * w3v[:, None] * s_ww) / s_ww  # [h2, h1]
@@ -468,27 +500,35 @@ def concat_step_f16(x, y, study_id, params, estimator: str, row_block: int = 64)
         z2 = F.linear(h, w2h) / (s_uv * s_w) + b2
         return pre, h, z2
 
-    s_all = torch.cat([F.linear(F.relu(block(s)[2]), w3, b3).squeeze(-1) for s in range(0, b, row_block)], 0)
+    s_all = _scores_pass(lambda s: F.linear(F.relu(block(s)[2]), w3, b3).squeeze(-1), b, row_block, r0, r1, scores_outside,
+                         progress, x.dtype)
     loss = bound_from_matrix(s_all, study_id, estimator)
     g = matrix_grad_scores(s_all, study_id)
+    negm = negative_mask(study_id)
+    g_max = max(float(g[negm].max()) if bool(negm.any()) else 0.0, 1.0 / b)
+    s_g = f16_pow2_scale(float(torch.tensor(g_max, dtype=torch.float32)), 13)
     du = torch.zeros_like(u)
     dv = torch.zeros_like(v)
     dmat = torch.zeros_like(w2)
     mvec = torch.zeros_like(b2)
-    for s in range(0, b, row_block):
+    for s in range(r0, r1, row_block):
+        e = min(s + row_block, r1)
         pre, h, z2 = block(s)
-        gb = g[s:s + row_block, :, None]
+        pre, h, z2 = pre[:e - s], h[:e - s], z2[:e - s]
+        gb = g[s:e, :, None]
         m = (z2 > 0).to(x.dtype)
         dh1 = gb * (pre > 0).to(x.dtype) * (m @ w2w)
-        du[s:s + row_block] = dh1.sum(1)
+        du[s:e] = dh1.sum(1)
         dv += dh1.sum(0)
         hf = round_f16(round_f16(gb * s_g) * h)
         dmat += torch.einsum("ijn,ijk->nk", m, hf) / (s_uv * s_g)
         mvec += (gb * m).sum((0, 1))
+        if progress is not None and ((s - r0) // row_block) % 8 == 0:
+            progress(f"oracle gradients: row {s} of [{r0}, {r1})")
     dparams = [torch.cat([du.t() @ x, dv.t() @ y], 1), dv.sum(0), w3v[:, None] * dmat, w3v * mvec,
-               ((w2 * dmat).sum(1) + b2 * mvec).reshape(w3.shape), g.sum().reshape(b3.shape)]
-    return {"scores": s_all, "loss": loss, "dx": du @ w1[:, :dx], "dy": dv @ w1[:, dx:], "dparams": dparams,
-            "scales": (s_uv, s_w, s_ww)}
+               ((w2 * dmat).sum(1) + b2 * mvec).reshape(w3.shape), g[r0:r1].sum().reshape(b3.shape)]
+    return {"scores": s_all, "loss": loss, "dx": (du @ w1[:, :dx])[r0:r1], "dy": dv @ w1[:, dx:], "dparams": dparams,
+            "scales": (s_uv, s_w, s_ww, s_g)}
 
 
 def concat_relu_flip_budget(x, y, params, margin: float, round_fn=None):

@@ -315,7 +315,22 @@ class OracleRawBilinearOps(OracleBilinearOps):
         return loss.reshape(1), stats, gx, gy, gp
 
 
-def run_raw(rank, world, port, b_local, d, estimator, out_dir):
+class OracleSplitTailOps(OracleRawBilinearOps):
+    """HipBilinearOps' split backward (merge_backward_tail / backward_dw, round 4): the step starts the reduce-scatter of
+    dY between the two; the call log pins the order."""
+
+    def merge_backward_tail(self, saved, records_all, n_pos, estimator, grad_out, out=None):
+        loss, stats, gx, gy, gp = OracleRawBilinearOps.merge_backward(self, saved, records_all, n_pos, estimator, grad_out)
+        self.calls[-1] = f"merge_backward_tail:{records_all.shape[0]}"
+        self._gp = gp
+        return loss, stats, gx, gy
+
+    def backward_dw(self, saved, out=None):
+        self.calls.append("backward_dw")
+        return self._gp
+
+
+def run_raw(rank, world, port, b_local, d, estimator, out_dir, split_tail=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from mutual_info_img_txt.distributed import GlobalBatchGraphStep
@@ -325,7 +340,15 @@ def run_raw(rank, world, port, b_local, d, estimator, out_dir):
     w = orc.hash_uniform((d, d), 99, torch.float64)
     codes = torch.from_numpy(orc.sid_to_int(sid))
     sl = slice(rank * b_local, (rank + 1) * b_local)
-    ops = OracleRawBilinearOps()
+    ops = OracleSplitTailOps() if split_tail else OracleRawBilinearOps()
+    if split_tail:  # log the start of the reduce-scatter too: it must fall between the two backward calls
+        import mutual_info_img_txt.distributed as dmod
+        start = dmod._reduce_scatter_rows_start
+
+        def logged(t, group):
+            ops.calls.append("reduce_scatter_start")
+            return start(t, group)
+        dmod._reduce_scatter_rows_start = logged
     st = GlobalBatchGraphStep(x[sl].contiguous(), y[sl].contiguous(), codes[sl].contiguous(), [w.clone()], estimator, "f32",
                               critic="bilinear", group=dist.group.WORLD, ops=ops, capture=False)
     st.step()

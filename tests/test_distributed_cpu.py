@@ -122,6 +122,27 @@ def test_split_forward_and_separable_two_ranks(tmp_path, variant, staged):
         assert torch.equal(a, c)
 
 
+def test_split_tail_overlaps_the_reduce_scatter(tmp_path):
+    """Round 4: the reduce-scatter of dY is STARTED between the backward's first launch (statistics, dX, partial dY) and its
+    dW launch (ops.merge_backward_tail / backward_dw), so that it runs beside the latter.  Two gloo ranks, oracle-backed ops
+    with the product ops' method names: the call log pins the order, the results equal the single-process oracle."""
+    world, b_local, d = 2, 6, 5
+    mp.spawn(dist_worker.run_raw, args=(world, _free_port(), b_local, d, "infonce", str(tmp_path), True), nprocs=world, join=True)
+    b = world * b_local
+    x, y, sid, _ = orc.synthetic_case(b, d, d, h1=8, h2=8, salt=21, dup=True, dtype=torch.float64)
+    w = orc.hash_uniform((d, d), 99, torch.float64)
+    ref = orc.matrix_step(lambda a, c, ww: orc.bilinear_scores(a, c, ww), [x, y, w], sid, "infonce")
+    outs = [torch.load(os.path.join(tmp_path, f"rank{r}.pt"), weights_only=True) for r in range(world)]
+    for r, o in enumerate(outs):
+        sl = slice(r * b_local, (r + 1) * b_local)
+        np.testing.assert_allclose(o["loss"].numpy().reshape(-1), ref["loss"].numpy().reshape(-1), rtol=1e-6, atol=1e-6)
+        np.testing.assert_allclose(o["dx"].numpy(), ref["grads"][0][sl].numpy(), rtol=1e-8, atol=1e-12)
+        np.testing.assert_allclose(o["dy"].numpy(), ref["grads"][1][sl].numpy(), rtol=1e-8, atol=1e-12)
+        np.testing.assert_allclose(o["dparams"][0].numpy(), ref["grads"][2].numpy(), rtol=1e-8, atol=1e-12)
+        assert o["calls"] == ["forward_raw", "merge_backward_tail:6", "reduce_scatter_start", "backward_dw"] * 2, o["calls"]
+    assert torch.equal(outs[0]["loss"], outs[1]["loss"]) and torch.equal(outs[0]["dparams"][0], outs[1]["dparams"][0])
+
+
 @pytest.mark.parametrize("estimator", ["dv", "infonce"])
 def test_raw_record_protocol_two_ranks(tmp_path, estimator):
     """The staged step's raw-record mode (ops.forward_raw / merge_backward: what the bilinear critic's fused kernels use on

@@ -359,15 +359,20 @@ CONCAT_CASES = [(40, 24, 40, 64, 256, True), (96, 128, 128, 1024, 512, False), (
                 (130, 32, 32, 64, 512, True)]
 
 
-# fp32 MFMA mode (exact fp32 products): scores |d| <= 2e-5*max(1,|S|max); loss 3e-5
+# fp32-tolerance modes -- "f32_exact"-style exact fp32 products (precision="f32" before round 4) and the two-part fp16
+# scheme "f16x3" (three MFMAs per product, csrc/mi_concat_f16.h): scores |d| <= 2e-5*max(1,|S|max); loss 3e-5
+F32_MODES = ["f32", "f16x3"]
+
+
+@pytest.mark.parametrize("precision", F32_MODES)
 @pytest.mark.parametrize("b,dx,dy,h1,h2,dup", CONCAT_CASES)
-def test_concat_f32_forward_vs_oracle(dev, b, dx, dy, h1, h2, dup):
+def test_concat_f32_forward_vs_oracle(dev, b, dx, dy, h1, h2, dup, precision):
     from mutual_info_img_txt import mi_critics
     x, y, sid, params = orc.synthetic_case(b, dx, dy, h1=h1, h2=h2, salt=b, dup=dup)
     mlp = _mlp_on(dev, dx + dy, (h1, h2), params)
     for est in ("dv", "infonce"):
         with torch.no_grad():
-            loss, scores = mi_critics.fused_mi_bound(x.to(dev), y.to(dev), sid, mlp, est, precision="f32",
+            loss, scores = mi_critics.fused_mi_bound(x.to(dev), y.to(dev), sid, mlp, est, precision=precision,
                                                      return_scores=True)
         s_ref = orc.concat_scores_matrix(x.double(), y.double(), [p.double() for p in params])
         l_ref = orc.bound_from_matrix(s_ref, sid, est)
@@ -377,9 +382,10 @@ def test_concat_f32_forward_vs_oracle(dev, b, dx, dy, h1, h2, dup):
         assert tuple(loss.shape) == ((1,) if est == "dv" else ())
 
 
+@pytest.mark.parametrize("precision", F32_MODES)
 @pytest.mark.parametrize("tag", ["b8_d768", "b32_d768", "b16_d128", "b32_d128", "b16_d768_dup", "b32_d128_dup",
                                  "b24_d96x160_dup"])
-def test_concat_f32_forward_golden(dev, golden, tag):
+def test_concat_f32_forward_golden(dev, golden, tag, precision):
     """Scores in reference row order and both losses against the outputs of the reference's own functions."""
     from mutual_info_img_txt import mi_critics
     from mutual_info_img_txt.main_utils import pair_index
@@ -390,7 +396,7 @@ def test_concat_f32_forward_golden(dev, golden, tag):
     pi, pj = pair_index(sid, dev)
     for est in ("dv", "infonce"):
         with torch.no_grad():
-            loss, scores = mi_critics.fused_mi_bound(x.to(dev), y.to(dev), sid, mlp, est, precision="f32",
+            loss, scores = mi_critics.fused_mi_bound(x.to(dev), y.to(dev), sid, mlp, est, precision=precision,
                                                      return_scores=True)
         rows = scores[pi.long(), pj.long()].cpu().numpy()
         ref = g[f"{tag}/f64/scores"]
@@ -433,11 +439,12 @@ GRAD_NAMES = ["dx", "dy", "dw1", "db1", "dw2", "db2", "dw3", "db3"]
 
 # fp32 MFMA mode, all gradients against the fp64 oracle: |d| <= 3e-4 * max|grad| (+ rtol 2e-3); db3 (true value 0,
 # addends O(1)): |d| <= 1e-5.
+@pytest.mark.parametrize("precision", F32_MODES)
 @pytest.mark.parametrize("b,dx,dy,h1,h2,dup", CONCAT_CASES)
 @pytest.mark.parametrize("est", ["dv", "infonce"])
-def test_concat_f32_backward_vs_oracle(dev, b, dx, dy, h1, h2, dup, est):
+def test_concat_f32_backward_vs_oracle(dev, b, dx, dy, h1, h2, dup, est, precision):
     x, y, sid, params = orc.synthetic_case(b, dx, dy, h1=h1, h2=h2, salt=b, dup=dup)
-    loss, scores, grads = _concat_step(dev, x, y, sid, params, (h1, h2), est, "f32")
+    loss, scores, grads = _concat_step(dev, x, y, sid, params, (h1, h2), est, precision)
     o = orc.concat_matrix_step(x.double(), y.double(), sid, [p.double() for p in params], est)
     refs = [o["dx"], o["dy"]] + list(o["dparams"])
     for name, got, ref in zip(GRAD_NAMES, grads, refs):
@@ -447,13 +454,14 @@ def test_concat_f32_backward_vs_oracle(dev, b, dx, dy, h1, h2, dup, est):
                                    err_msg=name)
 
 
+@pytest.mark.parametrize("precision", F32_MODES)
 @pytest.mark.parametrize("tag", ["b8_d768", "b32_d768", "b16_d768_dup", "b32_d128_dup", "b24_d96x160_dup"])
-def test_concat_f32_backward_golden(dev, golden, tag):
+def test_concat_f32_backward_golden(dev, golden, tag, precision):
     """dX, dY and digests of the critic-parameter gradients against the reference's own autograd (fp64 twins)."""
     g = golden("g3_full_step.npz")
     b, di, dt_, dup, salt = [int(v) for v in g[f"{tag}/meta"]]
     x, y, sid, params = orc.synthetic_case(b, di, dt_, salt=salt, dup=bool(dup))
-    loss, scores, grads = _concat_step(dev, x, y, sid, params, (1024, 512), "dv", "f32")
+    loss, scores, grads = _concat_step(dev, x, y, sid, params, (1024, 512), "dv", precision)
     k = f"{tag}/dv/f64"
     np.testing.assert_allclose(loss.cpu().numpy(), g[f"{k}/loss"], rtol=1e-5, atol=3e-5)
     for name, got in zip(("dx", "dy"), grads[:2]):

@@ -104,6 +104,147 @@ def test_config1_separable_bf16(dev, dup):
         assert err < 1.5e-2, (name, err)
 
 
+def _progress_file():
+    """Long host-side oracle runs: a line now and then into gpurun_out/ (a harness that kills silent commands sees progress)."""
+    path = os.path.join(ROOT, "gpurun_out", "oracle_progress.log")
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+
+    def note(msg):
+        with open(path, "a") as f:
+            f.write(msg + "\n")
+        print(msg, flush=True)
+    return note
+
+
+@pytest.mark.slow
+@pytest.mark.parametrize("precision", ["bf16", "f16"])
+@pytest.mark.parametrize("d", [512])
+def test_concat_all_gradients_config4_size(dev, d, precision):
+    """BASELINE config 4's own size -- B = 4096, h = 1024 / 512, 16.8 M pairs -- all eight gradients of the 16-bit kernels
+    against the oracle that rounds where they round.  The oracle's gradient pass over all 4096 rows
+    costs ~70 TFLOP of host work (more than seven SILENT minutes on the GPU box's 16 cores: the harness kills that), so the
+    default run checks the share of ONE rank of config 4 -- the 512-row block [1536, 2048) of the 4096 x 4096 pair matrix,
+    through the library's row-block entry points with the statistics of the whole batch (the eight blocks' records merged
+    in rank order), against the oracle's terms of those rows.  MI_RUN_FULL_ORACLE=1 runs the whole batch through the
+    one-call path against the whole oracle instead (run once per mode in round 4: profiles/r4_full_size_concat_parity.txt)."""
+    from mutual_info_img_txt import _hip
+    from mutual_info_img_txt.distributed import HipConcatMlpOps
+    from mutual_info_img_txt.mi_critics import _precision_code
+    b, h1, h2, G, blk = 4096, 1024, 512, 8, 3
+    note = _progress_file()
+    x, y, _, params = orc.synthetic_case(b, d, d, h1=h1, h2=h2, salt=b // 8)
+    sid = _dup_ids(b)
+    full = bool(os.environ.get("MI_RUN_FULL_ORACLE"))
+    br = b // G
+    r0, r1 = (0, b) if full else (blk * br, (blk + 1) * br)
+    prec = _precision_code(precision)
+    if full:
+        loss, grads = _concat_all_grads(dev, x, y, sid, params, (h1, h2), "dv", precision)
+    else:
+        ops = HipConcatMlpOps()
+        from mutual_info_img_txt.mi_critics import study_id_codes
+        sd = study_id_codes(sid, dev)
+        xd, yd = x.to(dev), y.to(dev)
+        pd = [p.to(dev) for p in params]
+        pd[4] = pd[4].reshape(-1).contiguous()
+        recs, saved, s_gpu = [], None, []
+        for g in range(G):
+            rec, sv = ops.forward(xd[g * br:(g + 1) * br].contiguous(), yd, pd, sd[g * br:(g + 1) * br].contiguous(), sd,
+                                  g * br, 0, prec, g == blk)
+            recs.append(rec)
+            s_gpu.append(sv[7].cpu())  # the block's score rows
+            if g == blk:
+                saved = sv
+        s_gpu = torch.cat(s_gpu, 0)
+        loss, stats = ops.merge(torch.stack(recs), b, 0)
+        gx, gy, gp = ops.backward(saved, stats, torch.ones(1, device=dev))
+        torch.cuda.synchronize()
+        loss, grads = loss.cpu(), [t.cpu() for t in [gx, gy] + list(gp)]
+    # fp32 oracle (half the host time of fp64; its blocked sums are good to ~1e-5, the tolerances here are 1e-2 .. 2e-2)
+    p32 = [p.float() for p in params]
+    xo, yo = x.float(), y.float()
+    rows = None if full else (r0, r1)
+    # default run: the scores of the seven OTHER blocks (they only enter the log-sum-exp and g) are the kernels' own --
+    # test_concat_full_size_sampled_rows_vs_oracle pins those against the oracle; the block's own rows are recomputed and
+    # compared below
+    outside = None if full else s_gpu
+    if precision == "bf16":
+        o = orc.concat_step_rounded(xo, yo, sid, p32, "dv", row_block=32, rows=rows, progress=note, scores_outside=outside)
+        margin, rf = 2.0 ** -8 * 2.0 * float(p32[2].abs().max()), orc.round_bf16
+    else:
+        o = orc.concat_step_f16(xo, yo, sid, p32, "dv", row_block=32, rows=rows, progress=note, scores_outside=outside)
+        # (U and V are rounded to fp16 BEFORE the add in this mode: where the fp32 oracle's first layer and the library's
+        # differ in the last bit, a U / V element lands on the neighbouring fp16 value and several of them move a Z2 by more
+        # than one ulp of H1 times |W2|: four ulps of margin)
+        margin, rf = 2.0 ** -9 * 2.0 * float(p32[2].abs().max()), orc.round_f16
+    if not full:
+        s_tol = (3e-3 if precision == "bf16" else 3e-4) * max(float(o["scores"].abs().max()), 1.0)
+        assert float((s_gpu[r0:r1] - o["scores"][r0:r1]).abs().max()) < s_tol
+    budget = orc.concat_relu_flip_budget(xo, yo, p32, margin, round_fn=rf)
+    sc = max(float(o["scores"].abs().max()), 1.0)
+    assert abs(float(loss.sum()) - float(o["loss"].sum())) < 3e-3 * sc
+    refs = [o["dx"], o["dy"]] + list(o["dparams"])
+    errs = {}
+    for name, got, ref in zip(GRAD_NAMES, grads, refs):
+        ref = ref.reshape(got.shape).double()
+        scale = 1.0 if name == "db3" else float(ref.abs().max())
+        err = (got.double() - ref).abs()
+        slack = budget.get(name)
+        if slack is not None:
+            slack = slack.reshape(-1, *got.shape[1:])[r0:r1] if name == "dx" else slack.reshape(got.shape)
+            err = (err - slack.double()).clamp_min(0.0)
+        errs[name] = float(err.max()) / scale
+    note(f"B=4096 d={d} {precision} rows [{r0}, {r1}): concat errors vs the rounded oracle: " +
+         str({k: f"{v:.2e}" for k, v in errs.items()}))
+    for name, err in errs.items():
+        assert err < (2e-5 if name == "db3" else 2e-2), (name, err, errs)
+
+
+@pytest.mark.parametrize("b,dx,dy,k,est", [(256, 256, 256, 256, "infonce"), (512, 192, 320, 128, "dv"), (1024, 512, 512, 512, "dv")])
+def test_separable_one_call_step(dev, b, dx, dy, k, est):
+    """mi_separable_step (round 4: five launches -- the bilinear critic's two-launch tail generalised to the two projections)
+    against the rounded oracle at the bf16 tolerances, and against the forward + backward calls (same rounding points,
+    other summation order: fp32 rounding apart).  configs[1]'s shape first."""
+    from mutual_info_img_txt import _hip
+    from mutual_info_img_txt.graphed import GraphedMiStep
+    from mutual_info_img_txt.model import SeparableCritic
+    gen = torch.Generator().manual_seed(b + k)
+    x = torch.randn(b, dx, generator=gen)
+    y = torch.randn(b, dy, generator=gen)
+    torch.manual_seed(b)
+    critic = SeparableCritic(dx, dy, k)
+    with torch.no_grad():
+        critic.wg.mul_(0.6)
+        critic.wh.mul_(0.6)
+    wg, wh = critic.wg.detach().clone(), critic.wh.detach().clone()
+    critic.to(dev)
+    sid = _dup_ids(b)
+    lib = _hip.load()
+    assert lib.mi_separable_path(b, b, dx, dy, k, _hip.MI_PREC_BF16) == _hip.MI_PATH_FUSED_TAIL
+    step = GraphedMiStep(critic, b, dx, dy, est, "bf16", dev, capture=True)
+    step.set_inputs(x.to(dev), y.to(dev), sid)
+    o = orc.separable_step_rounded(x, y, wg, wh, sid, est)
+    sc = max(float(o["scores"].abs().max()), 1.0)
+    # the two calls (finalize + slab reduce + two split-K launches)
+    step.forward()
+    step.backward()
+    torch.cuda.synchronize()
+    two = [step.loss_buf.clone(), step.grad_x.clone(), step.grad_y.clone(), step.grad_params[0].clone(), step.grad_params[1].clone()]
+    for mode in ("eager", "graph"):
+        for t in (step.grad_x, step.grad_y, *step.grad_params):
+            t.zero_()
+        loss = (step.step_eager() if mode == "eager" else step.step()).clone()
+        torch.cuda.synchronize()
+        assert abs(float(loss.sum()) - float(o["loss"].sum())) < 2e-3 * sc
+        assert abs(float(loss.sum()) - float(two[0].sum())) < 1e-5 * sc
+        assert _hip.stats_dict(step.stats)["n_neg"] == int(orc.negative_mask(sid).sum())
+        got = [step.grad_x, step.grad_y, step.grad_params[0], step.grad_params[1]]
+        for name, g, ref, t2 in zip(("dx", "dy", "dwg", "dwh"), got, (o["dx"], o["dy"], o["dwg"], o["dwh"]), two[1:]):
+            scale = float(ref.abs().max())
+            assert float((g.cpu().double() - ref).abs().max()) < 1.5e-2 * scale, (mode, name)
+            assert float((g - t2).abs().max()) < 2e-3 * scale, (mode, name)  # bf16 roundings of dA / dC may fall differently
+
+
 # ------------------------------------------------------------------------------------------------ fp32 parity at size
 @pytest.mark.parametrize("precision", ["f32_exact", "bf16x3"])
 @pytest.mark.parametrize("b,d", [(1024, 512), (4096, 512)])
@@ -210,24 +351,14 @@ def _concat_all_grads(dev, x, y, sid, params, hidden, est, precision):
 # B > 1024 makes plan_concat split rows over workgroups (rows_per_msplit > 1, rows_per_dsplit > 16, several i-blocks
 # and j-splits): the multi-row paths of the db2 / dw2 / finish_w2 / dV-slab / split-K dW1 kernels, with small widths so
 # that the fp64 oracle stays cheap.  And the reference's own widths (h = 1024 / 512) at B = 512, d = 768.
-#
-# The last case is BASELINE config 4's own size (B = 4096, d = 512, h = 1024 / 512: 16.8 M pairs): all eight gradients of
-# the 16-bit kernels against the rounded oracle, row-blocked.  The oracle needs ~70 TFLOP of host
-# work per mode (run in fp32 there: ~2.5 minutes on the box's 16 cores): marked `slow`, skipped with MI_SKIP_SLOW=1.
-@pytest.mark.parametrize("b,d,h1,h2,rb", [(1536, 32, 64, 256, 128), (2048, 32, 64, 256, 128), (512, 768, 1024, 512, 64),
-                                          pytest.param(4096, 512, 1024, 512, 32, marks=pytest.mark.slow)])
-@pytest.mark.parametrize("precision", ["f32", "bf16", "f16"])
+@pytest.mark.parametrize("b,d,h1,h2,rb", [(1536, 32, 64, 256, 128), (2048, 32, 64, 256, 128), (512, 768, 1024, 512, 64)])
+@pytest.mark.parametrize("precision", ["f32", "f16x3", "bf16", "f16"])
 def test_concat_all_gradients_at_size(dev, b, d, h1, h2, rb, precision):
-    if b >= 4096 and (precision == "f32" or os.environ.get("MI_SKIP_SLOW")):
-        pytest.skip("full-size case: 16-bit modes only (the fp32 kernels are covered up to B = 2048); MI_SKIP_SLOW skips it")
     x, y, _, params = orc.synthetic_case(b, d, d, h1=h1, h2=h2, salt=b // 8)
     sid = _dup_ids(b)
     loss, grads = _concat_all_grads(dev, x, y, sid, params, (h1, h2), "dv", precision)
-    # the full-size case runs the oracle in fp32 (half the host time: ~2.5 min on 16 cores instead of 5; its blocked sums
-    # are good to ~1e-5, the tolerances here are 1e-2 .. 2e-2)
-    odt = torch.float32 if b >= 4096 else torch.float64
-    p64 = [p.to(odt) for p in params]
-    x, y = x.to(odt), y.to(odt)
+    p64 = [p.double() for p in params]
+    x, y = x.double(), y.double()
     budget = {}
     if precision == "bf16":
         # the oracle that rounds where the forward AND the backward kernels round (closed-form backward) ...
@@ -248,13 +379,13 @@ def test_concat_all_gradients_at_size(dev, b, d, h1, h2, rb, precision):
     else:
         o = orc.concat_matrix_step(x, y, sid, p64, "dv", row_block=rb)
     sc = max(float(o["scores"].abs().max()), 1.0)
-    assert abs(float(loss) - float(o["loss"])) < (3e-5 + 1e-5 * abs(float(o["loss"])) if precision == "f32" else 3e-3 * sc)
+    assert abs(float(loss) - float(o["loss"])) < (3e-5 + 1e-5 * abs(float(o["loss"])) if precision in ("f32", "f16x3") else 3e-3 * sc)
     refs = [o["dx"], o["dy"]] + list(o["dparams"])
     errs = {}
     for name, got, ref in zip(GRAD_NAMES, grads, refs):
         ref = ref.reshape(got.shape)
         scale = 1.0 if name == "db3" else float(ref.abs().max())
-        if precision == "f32":
+        if precision in ("f32", "f16x3"):
             # 5e-4 (not the 3e-4 of the small cases): the fp32 MFMA accumulates each output over up to B^2 = 4 M addends
             # in a fixed sequential order; measured worst element 3.3e-4 * max|grad| at B = 512, h = 1024 / 512
             np.testing.assert_allclose(got.numpy(), ref.numpy(), rtol=2e-3, atol=(1e-5 if name == "db3" else 5e-4) * scale,
