@@ -52,13 +52,14 @@ PEAK_TFLOPS = {"bf16": 2500.0, "f16": 2500.0,  # fp16 MFMA runs at the bf16 rate
                "f32": 157.3,  # dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md
                "f32_exact": 157.3,       # v_mfma_f32_32x32x2_f32 products ("f32" on the bilinear critic runs bf16x3)
                "bf16x3": 2500.0 / 3,     # three bf16 MFMAs per algorithmic product
+               "f16x3": 2500.0 / 3,      # concat-MLP "f32": two-part fp16 operands, three MFMAs per product in the forward (two in the backward kernels)
                "fp8": 5000.0}            # the dense fp8 peak: the forward products run on v_mfma_scale_f32_32x32x64_f8f6f4
                                          # with unit block scales; the backward's contractions are bf16
 PEAK_HBM_GBS = 8000.0
 # the secondary leg (the reference's concat-MLP critic): fast 16-bit modes, the first one is the `secondary` number; and
 # the modes that hold the fp32 tolerances
 SECONDARY_FAST = {"concat_mlp": ["f16", "bf16"]}
-SECONDARY_PARITY = ["f32"]
+SECONDARY_PARITY = ["f32", "f32_exact"]  # "f32" = the two-part fp16 scheme (MI_PREC_F16X3); "f32_exact" = fp32-input MFMA
 
 
 def parse_args():
@@ -383,9 +384,13 @@ PMC_KERNEL_OF = {
     "bilinear dT = G Y | dY = G^T T": "gemm_bf16_pipe_kernel",
     "bilinear G": "gemm_bf16_big_kernel<mi::EpiGradScore2>",
     "bilinear score+LSE": "gemm_bf16_big_kernel<mi::EpiScoreLse2>",
-    "concat_fwd_kernel": "concat_fwd_dma_kernel",
-    "concat_bwd_duv_kernel": "concat_bwd_duv_kernel",
-    "concat_bwd_dw2_kernel": "concat_bwd_dw2_kernel",
+    # concat-MLP critic: a regular expression on the rocprofv3 kernel name (demangled or mangled form) per precision mode
+    "concat_fwd_kernel": {"bf16": r"concat_fwd_dma_kernel", "f16": r"concat_fwd_f16_kernel", "f16x3": r"concat_fwd_f16x3_kernel"},
+    "concat_bwd_duv_kernel": {"bf16": r"concat_bwd_duv3_kernel(<__bf16|IDF16b)",
+                              "f16": r"concat_bwd_duv3_kernel(<_Float16, _Float16|IDF16_DF16_)",
+                              "f16x3": r"concat_bwd_duv3_kernel(<_Float16, float|IDF16_f)"},
+    "concat_bwd_dw2_kernel": {"bf16": r"concat_bwd_dw2_kernel(<__bf16|IDF16b)", "f16": r"concat_bwd_dw2_f16_kernel",
+                              "f16x3": r"concat_bwd_dw2_kernel(<_Float16|IDF16_)"},
 }
 
 
@@ -398,13 +403,14 @@ def csrc_sha():
     return h.hexdigest()[:12]
 
 
-def measured_counters(name, b, d):
+def measured_counters(name, b, d, mode="bf16"):
     """HBM bytes per launch and MFMA-busy fraction of a kernel from the newest committed PMC pass
     (tools/profile_round.sh: FETCH_SIZE, WRITE_SIZE and the SQ counters in separate rocprofv3 --pmc runs, gfx950
     corrections applied there).  bench.py cannot run the profiler itself; it REFUSES a pass whose recorded source
     fingerprint differs from the sources of this build (a stale pass would silently describe other kernels), and only
     accepts the configuration those passes ran (B=4096, d=512, one GPU)."""
-    if (b, d) != (4096, 512) or name not in PMC_KERNEL_OF:
+    # (the PMC passes run bench.py's defaults: the headline at d = 512, the concat-MLP leg at d = 768)
+    if name not in PMC_KERNEL_OF or (b, d) != ((4096, 768) if name.startswith("concat") else (4096, 512)):
         return None
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
     if not files:
@@ -417,8 +423,13 @@ def measured_counters(name, b, d):
     src = os.path.basename(files[-1])
     if doc.get("csrc_sha") != csrc_sha():
         return {"stale": True, "source": src, "note": "PMC pass predates the current kernel sources: not attached"}
+    import re
+    want = PMC_KERNEL_OF[name]
+    want = want.get(mode) if isinstance(want, dict) else re.escape(want)
+    if not want:
+        return None
     for key, val in doc.get("kernels", {}).items():
-        if PMC_KERNEL_OF[name] in key:
+        if re.search(want, key):
             return {"bytes": round(val["total_bytes"]), "fetch": round(val["fetch_bytes"]), "write": round(val["write_bytes"]),
                     "mfma_busy_frac": val.get("mfma_busy_frac"), "source": src, "commit": doc.get("commit")}
     return None
@@ -435,7 +446,7 @@ def roofline_of(kernels, br, b, d, precision):
                 "traffic": None, "avg_us": k["ms_avg"] * 1e3}
     achieved = fl / (k["ms_avg"] * 1e-3) / 1e12
     peak = PEAK_TFLOPS[precision]
-    c = measured_counters(name, b, d) if br == b else None
+    c = measured_counters(name, b, d, precision) if br == b else None
     ok = c is not None and not c.get("stale")
     return {"kernel": name, "bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
             "frac": round(achieved / peak, 4), "traffic": c["bytes"] if ok else None,
@@ -546,10 +557,10 @@ def main():
     b, d, br = args.batch, args.dim, args.batch // world
 
     def run(kind, steps, warmup, precision=None, timed_iters=0, batch=None, dim=None, clock_ms=None, cold_first=False,
-            boundary="f32"):
-        st = Stepper(kind, args, rank, world, device, group, precision=precision, graph=want_graph, batch=batch, dim=dim,
-                     boundary=boundary)
-        if args.graph == "auto":
+            boundary="f32", probe=True):
+        st = Stepper(kind, args, rank, world, device, group, precision=precision, graph=want_graph and probe, batch=batch,
+                     dim=dim, boundary=boundary)
+        if args.graph == "auto" and probe:
             st.choose_launch_mode(world)
         # the contract's W + K steps from a young process first (no clock warm-up): `cold_ms_per_step`
         st.cold_elapsed = timed_run(st, steps, warmup, world) if cold_first else None
@@ -692,14 +703,16 @@ def main():
         fl3 = algorithmic_flops(other, b, d2, d2)
 
         def leg(mode, n):
-            st3, el3, k3, _ = run(other, n, 2, precision=mode, dim=d2)
+            # (steps of tens to hundreds of milliseconds: direct calls, no launch-mode probe, a short clock warm-up)
+            st3, el3, k3, _ = run(other, n, 1, precision=mode, dim=d2, probe=False, clock_ms=min(args.clock_warmup_ms, 100.0))
             ms3 = el3 / n * 1e3
-            peak = PEAK_TFLOPS[mode] * world
+            peak_key = "f16x3" if (other == "concat_mlp" and mode == "f32") else mode
+            peak = PEAK_TFLOPS[peak_key] * world
             res = {"precision": mode, "value": round(b / (ms3 * 1e-3), 1), "unit": "pairs/s", "ms_per_step": round(ms3, 4),
                    "steps": n, "hip_graph": not st3.use_eager, "loss": st3.loss(),
                    "step_algorithmic_tflops": round(fl3 / (ms3 * 1e-3) / 1e12, 2),
                    "step_frac_of_peak": round(fl3 / (ms3 * 1e-3) / 1e12 / peak, 5), "peak": round(peak, 1),
-                   "roofline": roofline_of(k3, br, b, d2, mode),
+                   "roofline": roofline_of(k3, br, b, d2, peak_key),
                    "kernels_us": {k: round(v["ms_avg"] * 1e3, 2) for k, v in sorted(k3.items(), key=lambda kv: -kv[1]["ms_total"])}}
             del st3
             torch.cuda.empty_cache()

@@ -404,8 +404,8 @@ static int bilinear_bwd_small(int64_t br, int64_t dx, int64_t dy, float* grad_x,
 // the scales a single GPU would have used.
 static int fp8_stage0(const float* x, const float* y, const float* w, int64_t br, int64_t b, int64_t dx, int64_t dy,
                       const BilinearPlan& p, hipStream_t st) {
-  const hipError_t e = hipMemsetAsync(p.f8sc, 0, sizeof(Fp8Scales), st);
-  if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync(fp8 scales)");
+  const int rc0 = launch_zero_words(p.f8sc, sizeof(Fp8Scales), st, "zero_words_kernel(fp8 scales)");
+  if (rc0) return rc0;
   AbsmaxJobs aj{};
   aj.in[0] = x; aj.n[0] = br * dx; aj.slot[0] = 0;
   aj.in[1] = y; aj.n[1] = b * dy; aj.slot[1] = 1;

@@ -50,6 +50,19 @@ struct ProfScope {
 
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+// Zeroes a few dwords of workspace (absmax slots) AS A KERNEL.  hipMemsetAsync did the job on an eager stream, but
+// captured into a hipGraph the memset node did not stay ordered between the kernels around it on the second and later
+// replays (round 4: the fp16 scales of a replayed concat step differed from the eager call's, gradients off by 1e-3);
+// a kernel node is ordered like every other launch of the capture.
+static __global__ void zero_words_kernel(unsigned* p, int n) {
+  for (int e = threadIdx.x; e < n; e += 64) p[e] = 0u;
+}
+static inline int launch_zero_words(void* p, size_t bytes, hipStream_t st, const char* what) {
+  hipLaunchKernelGGL(zero_words_kernel, dim3(1), dim3(64), 0, st, (unsigned*)p, (int)(bytes / 4));
+  const hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : hip_fail(e, what);
+}
+
 // Bump allocator over the caller's workspace (never allocates).
 struct Workspace {
   char* base;

@@ -401,8 +401,8 @@ int mi_concat_mlp_fwd(const float* x, const float* y, const float* w1, const flo
   unsigned* bitsN = need_grad ? p.bitsN : nullptr;
   if (precision == MI_PREC_F16X3) {
     // the fp32-tolerance mode: scaled fp32 U, V, two-part fp16 W2, three MFMAs per product (mi_concat_f16.h)
-    const hipError_t e0 = hipMemsetAsync(p.f16sc, 0, sizeof(F16Scales), st);
-    if (e0 != hipSuccess) return hip_fail(e0, "hipMemsetAsync(fp16 scales)");
+    rc = launch_zero_words(p.f16sc, sizeof(F16Scales), st, "zero_words_kernel(fp16 scales)");
+    if (rc) return rc;
     F16AbsmaxJobs aj{{p.u, p.v, w2, w3}, {b_rows * h1, b * h1, h2 * h1, h2}, p.f16sc};
     {
       ProfScope prof_("f16 absmax U V W2 w3", st);
@@ -427,8 +427,8 @@ int mi_concat_mlp_fwd(const float* x, const float* y, const float* w1, const flo
     rc = MI_OK;
   } else if (precision == MI_PREC_F16) {
     // absmax of U, V, W2, w3 -> power-of-two scales (device side) -> fp16 operand copies -> the packed-generation kernel
-    const hipError_t e0 = hipMemsetAsync(p.f16sc, 0, sizeof(F16Scales), st);
-    if (e0 != hipSuccess) return hip_fail(e0, "hipMemsetAsync(fp16 scales)");
+    rc = launch_zero_words(p.f16sc, sizeof(F16Scales), st, "zero_words_kernel(fp16 scales)");
+    if (rc) return rc;
     F16AbsmaxJobs aj{{p.u, p.v, w2, w3}, {b_rows * h1, b * h1, h2 * h1, h2}, p.f16sc};
     {
       ProfScope prof_("f16 absmax U V W2 w3", st);

@@ -26,17 +26,24 @@ PRECISIONS = {"f32": MI_PREC_F32, "fp32": MI_PREC_F32, "float32": MI_PREC_F32, "
 F32_NAMES = ("f32", "fp32", "float32")
 
 
-def resolve_precision(precision: str, bilinear_with_weight: bool, shapes=()) -> int:
+def resolve_precision(precision: str, bilinear_with_weight: bool, shapes=(), concat_hidden=None) -> int:
     """Precision name -> C-ABI code.  "f32" (the default of the Python interface: the reference is fp32 throughout) means
     "results within the stated fp32 tolerances" (DESIGN.md section 2).  For the bilinear critic those tolerances are met
     by MI_PREC_BF16X3 -- every operand as two bf16 parts, three bf16 MFMAs per product, fp32 accumulation -- at 6 - 7 times
     the speed of the exact fp32-input MFMA (0.35 ms against 2.3 ms per step at B = 4096, d = 512), so that is what "f32"
-    runs there when every size is a multiple of 8; "f32_exact" insists on exact fp32 products (v_mfma_f32_32x32x2_f32).
-    Other critics and shapes: "f32" is the exact mode."""
+    runs there when every size is a multiple of 8.  For the reference's make_mlp critic (``concat_hidden`` = (h1, h2)) they
+    are met by MI_PREC_F16X3 -- two-part fp16 operands, three MFMAs per product in the forward, two in the backward
+    kernels -- at a third of the exact mode's time (105 ms against >= 337 ms per step at B = 4096, h = 1024 / 512); that is
+    what "f32" runs there on the shapes of the fused kernels (h1 % 64 == 0, h2 in {256, 512}).  "f32_exact" insists on exact
+    fp32 products (v_mfma_f32_32x32x2_f32).  Other critics and shapes: "f32" is the exact mode."""
     if precision not in PRECISIONS:
         raise ValueError(f"unknown precision {precision!r}: expected one of {sorted(PRECISIONS)}")
     if precision in F32_NAMES and bilinear_with_weight and shapes and all(int(v) % 8 == 0 for v in shapes):
         return MI_PREC_BF16X3
+    if precision in F32_NAMES and concat_hidden is not None:
+        h1, h2 = (int(v) for v in concat_hidden)
+        if h1 >= 64 and h1 % 64 == 0 and h2 in (256, 512):
+            return MI_PREC_F16X3
     return PRECISIONS[precision]
 STATS_BYTES = 64
 RECORD_FLOATS = 8

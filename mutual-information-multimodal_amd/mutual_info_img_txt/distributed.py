@@ -439,13 +439,15 @@ class GlobalBatchCriticFn(torch.autograd.Function):
         return (None, None, None, None, None, gx, gy, *gparams)
 
 
-def _sharded_precision(precision: str, critic: str, x, y) -> int:
+def _sharded_precision(precision: str, critic: str, x, y, params=None) -> int:
     """The same name -> code resolution as on one GPU (_hip.resolve_precision): "f32" on the bilinear critic is the bf16x3
     scheme where every size is a multiple of 8 (fp32 tolerances at a sixth of the time), exact fp32 products otherwise and
     under "f32_exact" -- so that a precision name means the same numerics and speed on one GPU and on a sharded batch."""
     from .mi_critics import _precision_code
     if critic == "bilinear" and x.dim() == 2 and y.dim() == 2:
         return _hip.resolve_precision(precision, True, (x.shape[0], x.shape[1], y.shape[1]))
+    if critic == "concat_mlp" and params is not None and len(params) == 6:
+        return _hip.resolve_precision(precision, False, concat_hidden=(params[0].shape[0], params[2].shape[0]))
     return _precision_code(precision)
 
 
@@ -460,7 +462,7 @@ def global_batch_mi_bound(embedding_img, embedding_txt, study_id_codes, critic_p
     if ops is None:
         ops = {"bilinear": HipBilinearOps, "separable": HipSeparableOps, "concat_mlp": HipConcatMlpOps}[critic]()
     est = _estimator_code(estimator)
-    prec = _sharded_precision(precision, critic, embedding_img, embedding_txt)
+    prec = _sharded_precision(precision, critic, embedding_img, embedding_txt, critic_params)
     loss, stats = GlobalBatchCriticFn.apply(ops, group, est, prec, study_id_codes, embedding_img, embedding_txt,
                                             *critic_params)
     loss = loss if estimator == "dv" else loss.reshape(())
@@ -494,7 +496,7 @@ class GlobalBatchGraphStep:
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
         self.ops = ops if ops is not None else {"bilinear": HipBilinearOps, "separable": HipSeparableOps, "concat_mlp": HipConcatMlpOps}[critic]()
-        self.est, self.prec = _estimator_code(estimator), _sharded_precision(precision, critic, x, y)
+        self.est, self.prec = _estimator_code(estimator), _sharded_precision(precision, critic, x, y, params)
         self.x, self.y, self.sid = x.detach(), y.detach(), sid
         self.params = [p.detach() for p in params]
         for t in (self.x, self.y, self.sid, *self.params):

@@ -60,6 +60,7 @@ class GraphedMiStep:
             self.kind = "concat_mlp"
             w1, b1, w2, b2, w3, b3 = _concat_params(critic)
             self.params = [w1, b1, w2, b2, w3, b3]
+            self.prec = _hip.resolve_precision(precision, False, concat_hidden=(w1.shape[0], w2.shape[0]))  # "f32" -> f16x3
         for p in self.params:
             if p.device != dev or p.dtype != torch.float32 or not p.is_contiguous():
                 raise ValueError("critic parameters must be contiguous float32 tensors on the step's device")

@@ -358,6 +358,8 @@ def fused_mi_bound(embedding_img: torch.Tensor, embedding_txt: torch.Tensor, stu
             scores = None
     else:
         w1, b1, w2, b2, w3, b3 = _concat_params(critic)
+        # "f32" on the reference's critic: fp32-grade results from the two-part fp16 scheme (_hip.resolve_precision)
+        prec = _hip.resolve_precision(precision, False, concat_hidden=(w1.shape[0], w2.shape[0]))
         if w1.shape[1] != embedding_img.shape[1] + embedding_txt.shape[1]:
             raise ValueError(f"critic expects {w1.shape[1]} inputs, embeddings give "
                              f"{embedding_img.shape[1]} + {embedding_txt.shape[1]}")

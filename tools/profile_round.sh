@@ -8,6 +8,7 @@
 # rocprofv3 runs from /tmp with the program directly after `--` (profiling recipe of the GPU pool).
 set -u
 TAG=${1:-r1_x}
+COMMIT=${2:-unknown}   # the snapshot on the GPU box has no .git: pass `git rev-parse --short HEAD` as the second argument
 REPO=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$REPO/gpurun_out/profile_$TAG
 rm -rf "$OUT"; mkdir -p "$OUT"
@@ -23,7 +24,7 @@ rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/write" -o
 # GRBM_GUI_ACTIVE / 8 = the kernel's duration in shader cycles (sum over the 8 XCDs); 1024 SIMDs on the chip
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d "$OUT/sq" -o sq -- $SHORT > "$OUT/sq.log" 2>&1 || echo "SQ pass failed (kept going)"
 CSRC_SHA=$(python3 -c "import sys; sys.path.insert(0, '$REPO'); import bench; print(bench.csrc_sha())" 2>/dev/null | tail -1)
-python3 - "$OUT" "$TAG" "$CSRC_SHA" <<'PY'
+python3 - "$OUT" "$TAG" "$CSRC_SHA" "$COMMIT" <<'PY'
 import csv, glob, json, sys, collections
 out, tag, csrc_sha = sys.argv[1], sys.argv[2], sys.argv[3]
 def load(sub, counter):
@@ -49,6 +50,7 @@ def load2(sub, counter):
 f2, w2 = load2("fetch", "FETCH_SIZE"), load2("write", "WRITE_SIZE")
 mf, ga = load2("sq", "SQ_VALU_MFMA_BUSY_CYCLES"), load2("sq", "GRBM_GUI_ACTIVE")
 res["csrc_sha"] = csrc_sha  # bench.py attaches this file's numbers only to a build of the same kernel sources
+res["commit"] = sys.argv[4] if len(sys.argv) > 4 else None
 res["mfma_note"] = ("mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 * 1024): busy cycles of the matrix pipes "
                     "over (kernel duration in shader cycles x 1024 SIMDs)")
 for key in sorted(set(f2) | set(w2)):
