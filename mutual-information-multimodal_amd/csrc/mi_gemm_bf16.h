@@ -912,6 +912,10 @@ struct PipeCfg {
   __device__ static __forceinline__ int swz(int row) { return KT == 64 ? (row >> 1) & 7 : (row >> 2) & 3; }
 };
 using PipeCfg128 = PipeCfg<128, 128, 64, 2, 2, 2>;
+// 256 x 128 tile, waves 2 x 2 x 2 K groups, each 128 x 64: for two long-K problems whose N is 768 or 1024 (dT | dY of the
+// G-materialising path at the reference's embedding width): 2 x 16 x 6 = 192 / 2 x 16 x 8 = 256 workgroups at B = 4096,
+// where 128 x 128 tiles make 384 / 512 (one and a half / two rounds of workgroups) and 256 x 256 tiles 96 / 128
+using PipeCfg256x128 = PipeCfg<256, 128, 64, 2, 2, 2>;
 
 template <int N>
 __device__ __forceinline__ void wait_vmcnt_barrier() {
@@ -1072,25 +1076,29 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_pipe_kernel(GemmBf16Args arg
   MI_STAMP(4);
   if constexpr (Cfg::KG == 2) {
     // add the second K group's accumulators: [wmn][register 0..63][lane] fp32 = 64 KB
+    // (one 64-row half of the wave tile at a time: the 256-row shape has two)
     float* red = reinterpret_cast<float*>(smem_raw) + wmn * 4096 + lane;
-    if (kgrp == 1) {
 #pragma unroll
-      for (int a = 0; a < 2; ++a)
+    for (int h = 0; h < Cfg::TM / 2; ++h) {
+      if (kgrp == 1) {
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+        for (int a = 0; a < 2; ++a)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) red[((a * 2 + b) * 16 + r) * 64] = acc[0][a][b][r];
+          for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) red[((a * 2 + b) * 16 + r) * 64] = acc[h][a][b][r];
+      }
+      __syncthreads();
+      if (kgrp == 0) {
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[h][a][b][r] += red[((a * 2 + b) * 16 + r) * 64];
+      }
+      __syncthreads();  // the next half / the epilogue's staging areas overlap other waves' parts of `red`
     }
-    __syncthreads();
-    if (kgrp == 0) {
-#pragma unroll
-      for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) acc[0][a][b][r] += red[((a * 2 + b) * 16 + r) * 64];
-    }
-    __syncthreads();  // the epilogue's staging areas overlap other waves' parts of `red`
     if (kgrp == 1) return;
   }
   const int64_t mb = m0 + wm * (Cfg::BM / Cfg::WM), nb = n0 + wn * (Cfg::BN / Cfg::WN);
@@ -1334,6 +1342,26 @@ static inline int launch_gemm_bf16(const GemmBf16Args& args_in, int n_splits, co
   if constexpr (!Epi::kReducesPartial)
     big2 = !no_big2 && dma_ok && args.n_problems == 2 && n_splits == 1 && args.p[0].k >= 2048 && args.p[1].k >= 2048 &&
            !gemm_old_kernels() && 2 * ((mm + 255) / 256) * ((nn + 255) / 256) >= 192;
+  // long K, N too wide for one round of 128 x 128 tiles, too narrow to fill the chip with 256 x 256 ones: 256 x 128 tiles on
+  // the ping-pong kernel when they make one round that fills at least 5/8 of the CUs.  MI_GEMM_NO_P256=1: A/B switch.
+  if constexpr (!Epi::kReducesPartial) {
+    static const bool no_p256 = getenv("MI_GEMM_NO_P256") != nullptr;
+    const int64_t t128 = ((mm + 127) / 128) * ((nn + 127) / 128) * args.n_problems;
+    const int64_t t256 = ((mm + 255) / 256) * ((nn + 127) / 128) * args.n_problems;
+    if (!big2 && !no_p256 && dma_ok && n_splits == 1 && args.p[0].k >= 2048 && !gemm_old_kernels() && t128 > 256 &&
+        t256 <= 256 && t256 >= 160 && !(args.n_problems == 1 && gemm_bf16_use_big(mm, nn, args.p[0].k))) {
+      MI_SET_DYN_SMEM((gemm_bf16_pipe_kernel<PipeCfg256x128, Epi>), PipeCfg256x128::SMEM,
+                      "hipFuncSetAttribute(gemm_bf16_pipe_kernel 256x128)");
+      dim3 grid((unsigned)((nn + 127) / 128), (unsigned)((mm + 255) / 256), (unsigned)args.n_problems);
+      MI_STAMP_SELECT(what, st);
+      {
+        ProfScope prof_(what, st);
+        hipLaunchKernelGGL((gemm_bf16_pipe_kernel<PipeCfg256x128, Epi>), grid, dim3(512), PipeCfg256x128::SMEM, st, args, epi);
+      }
+      MI_LAUNCH_CHECK(what);
+      return MI_OK;
+    }
+  }
   if (big2 || (dma_ok && args.n_problems == 1 && n_splits == 1 && gemm_bf16_use_big(mm, nn, args.p[0].k))) {
     MI_SET_DYN_SMEM((gemm_bf16_big_kernel<Epi>), kG2SmemBig, "hipFuncSetAttribute(gemm_bf16_big_kernel)");
     dim3 grid((unsigned)((nn + 255) / 256), (unsigned)((mm + 255) / 256), (unsigned)args.n_problems);

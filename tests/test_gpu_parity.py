@@ -345,6 +345,36 @@ def test_bilinear_full_size_vs_oracle(dev, ids):
         assert err < 1e-2, (name, err)
 
 
+@pytest.mark.parametrize("d", [768, 1024])
+def test_bilinear_reference_width_vs_oracle(dev, d):
+    """B = 4096 at the reference's embedding width (768: model.py:308-309, 365, 552) and at 1024: outside the fused B x B
+    kernel (widths 128 / 256 / 512), so the step runs the G-materialising products -- dT | dY on the 256 x 128 ping-pong
+    tiles (mi_gemm_bf16.h, PipeCfg256x128).  Same oracle and tolerances as the headline size."""
+    from mutual_info_img_txt import _hip, mi_critics
+    from mutual_info_img_txt.model import BilinearCritic
+    b = 4096
+    assert _hip.load().mi_bilinear_path(b, b, d, d, _hip.MI_PREC_BF16) == _hip.MI_PATH_GEMMS
+    gen = torch.Generator().manual_seed(d)
+    x = torch.randn(b, d, generator=gen)
+    y = torch.randn(b, d, generator=gen)
+    w = torch.randn(d, d, generator=gen) * (0.3 / d ** 0.5)
+    sid = _survey_dup_ids(b)
+    critic = BilinearCritic(d, d)
+    with torch.no_grad():
+        critic.weight.copy_(w)
+    critic.to(dev)
+    xl, yl = x.to(dev).requires_grad_(True), y.to(dev).requires_grad_(True)
+    loss, stats = mi_critics.fused_mi_bound(xl, yl, sid.to(dev), critic, "infonce", precision="bf16", return_stats=True)
+    loss.sum().backward()
+    o = orc.bilinear_step_rounded(x, y, w, sid, "infonce")
+    assert _hip.stats_dict(stats)["n_neg"] == int(orc.negative_mask(sid).sum())
+    sc = float(o["scores"].abs().max())
+    assert abs(float(loss) - float(o["loss"])) < 2e-3 * max(sc, 1.0)
+    for name, got, ref in (("dx", xl.grad, o["dx"]), ("dy", yl.grad, o["dy"]), ("dw", critic.weight.grad, o["dw"])):
+        err = float((got.cpu().double() - ref).abs().max()) / float(ref.abs().max())
+        assert err < 1e-2, (name, err)
+
+
 # ------------------------------------------------------------------------------------------------ fused concat-MLP
 def _mlp_on(dev, d_in, hidden, params):
     from mutual_info_img_txt.model import make_mlp
