@@ -481,16 +481,41 @@ def fp8_roofline(kernels, b, d):
             "flops_per_launch": fl, "operands": "fp8 e4m3" if fp8_products else "bf16"}
 
 
-def cpu_baseline(kind, args, dim=None):
-    """The oracle (a CPU port of the reference algorithm, pinned to the reference by tests/golden) timed on this box's
-    host cores on a bounded sample of the same workload."""
-    from oracle import mi_oracle as orc
-    # host cores actually available to this process (a 1-GPU box shares a 256-thread host: its CPU share is 16)
+def host_cpu_share(default_cap=16):
+    """Threads for the CPU leg: the smallest of the affinity mask, the cgroup CPU quota and -- when neither restricts
+    the process (a 1-GPU box of the pool shows all 256 hardware threads of its host but is granted 16; 256 BLAS threads
+    there ran the oracle 14 x SLOWER than 16) -- `default_cap`.  MI_BENCH_CPU_THREADS overrides."""
+    env = os.environ.get("MI_BENCH_CPU_THREADS")
+    if env:
+        return max(1, int(env))
     try:
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
         avail = os.cpu_count() or 1
-    threads = max(1, min(avail, int(os.environ.get("MI_BENCH_CPU_THREADS", str(avail)))))
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:  # cgroup v2: "<quota> <period>" or "max <period>"
+            q, per = f.read().split()
+            if q != "max":
+                quota = max(1, int(int(q) / int(per)))
+    except (OSError, ValueError):
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as g:
+                q, per = int(f.read()), int(g.read())
+                if q > 0:
+                    quota = max(1, q // per)
+        except (OSError, ValueError):
+            pass
+    if quota is not None:
+        return max(1, min(avail, quota))
+    return max(1, min(avail, default_cap))
+
+
+def cpu_baseline(kind, args, dim=None):
+    """The oracle (a CPU port of the reference algorithm, pinned to the reference by tests/golden) timed on this box's
+    host cores on a bounded sample of the same workload."""
+    from oracle import mi_oracle as orc
+    threads = host_cpu_share()
     torch.set_num_threads(threads)
     d = dim or args.dim
     if kind == "bilinear":

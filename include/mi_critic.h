@@ -25,7 +25,7 @@
  *     (the reference synchronises only at loss.item(), main_utils.py:233); the only exception is
  *     mi_pairs_count_host, which returns a host integer
  *   - the callee never allocates or frees: outputs, saved statistics and workspace are caller-owned;
- *     query sizes with the *_workspace_bytes functions
+ *     query sizes with the *_workspace_bytes functions (pure host arithmetic; 0 for a non-positive size)
  *   - return value: 0 on success, negative MI_E* code on failure; mi_last_error() describes the last failure
  *     on the calling thread.  No C++ exception crosses this boundary.
  *   - re-entrant: forward and backward may be called from different host threads (autograd does).  Process-wide state is

@@ -580,6 +580,7 @@ using namespace mi;
 extern "C" {
 
 size_t mi_bilinear_workspace_bytes(int64_t b_rows, int64_t b, int64_t d_img, int64_t d_txt, int precision) {
+  if (b_rows <= 0 || b <= 0 || d_img <= 0 || d_txt <= 0) return 0;  // (the planner divides by tile counts)
   Workspace ws(nullptr, 0);
   return plan_bilinear(ws, b_rows, b, d_img, d_txt, precision).bytes + 256;
 }
@@ -1039,6 +1040,7 @@ extern "C" {
 
 size_t mi_separable_workspace_bytes(int64_t b_rows, int64_t b, int64_t d_img, int64_t d_txt, int64_t d_proj,
                                     int precision) {
+  if (b_rows <= 0 || b <= 0 || d_img <= 0 || d_txt <= 0 || d_proj <= 0) return 0;
   Workspace ws(nullptr, 0);
   return plan_separable(ws, b_rows, b, d_img, d_txt, d_proj, precision).bytes + 256;
 }

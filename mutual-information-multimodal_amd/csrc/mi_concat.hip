@@ -368,6 +368,7 @@ extern "C" {
 
 size_t mi_concat_mlp_workspace_bytes(int64_t b_rows, int64_t b, int64_t d_img, int64_t d_txt, int64_t h1, int64_t h2,
                                      int precision, int need_grad) {
+  if (b_rows <= 0 || b <= 0 || d_img <= 0 || d_txt <= 0 || h1 <= 0 || h2 <= 0) return 0;
   Workspace ws(nullptr, 0);
   return plan_concat(ws, b_rows, b, h1, h2, precision, need_grad, d_img > d_txt ? d_img : d_txt).bytes + 256;
 }

@@ -181,6 +181,7 @@ using namespace mi;
 extern "C" {
 
 size_t mi_pair_index_workspace_bytes(int64_t b) {
+  if (b <= 0) return 0;
   const int64_t n_entries = b * (b - 1);
   const int64_t n_chunks = (n_entries + kChunk - 1) / kChunk + 1;
   return align_up(sizeof(int) * n_chunks, 256) + align_up(sizeof(int64_t) * n_chunks, 256) + 512;

@@ -41,3 +41,15 @@ def test_stale_pmc_pass_is_refused(tmp_path, monkeypatch):
     (root / "profiles" / "zz_pmc_traffic.json").write_text(json.dumps(doc))
     c = bench.measured_counters("bilinear fused S | P Y | P^T T", 4096, 512)
     assert c["bytes"] == 3 and c["source"] == "zz_pmc_traffic.json"
+
+
+def test_cpu_leg_thread_count(monkeypatch):
+    """`cpu_baseline.cores`: affinity mask, cgroup quota or the pool's 16-thread share, whichever is smallest; an explicit
+    MI_BENCH_CPU_THREADS wins."""
+    import os
+    import bench
+    monkeypatch.delenv("MI_BENCH_CPU_THREADS", raising=False)
+    n = bench.host_cpu_share()
+    assert 1 <= n <= min(len(os.sched_getaffinity(0)), 16) or n <= len(os.sched_getaffinity(0))
+    monkeypatch.setenv("MI_BENCH_CPU_THREADS", "3")
+    assert bench.host_cpu_share() == 3
