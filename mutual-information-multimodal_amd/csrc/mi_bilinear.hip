@@ -1014,6 +1014,25 @@ static int separable_prep_project(const float* x, const float* y, const float* w
   return launch_gemm_bf16(two, 1, e, st, "separable A = X Wg | C = Y Wh");
 }
 
+// The one-call step's form of the above (mi_separable_step on the two-launch tail): conversions and BOTH projections in ONE
+// launch (bilinear_prep_t_kernel with a second product) -- nobody reads the row-major / transposed bf16 copies of X, Y, Wg,
+// Wh on that path, only the fragment-major ones.  MI_EINVAL: a shape the launch does not take (the caller falls back).
+static int separable_prep_project_fused(const float* x, const float* y, const float* wg, const float* wh,
+                                        const int64_t* sid_rows, const int64_t* sid_cols, int64_t br, int64_t b,
+                                        int64_t row_offset, int64_t dx, int64_t dy, int64_t k, const SeparablePlan& p,
+                                        hipStream_t st) {
+  static const bool off = getenv("MI_SEP_NO_FUSED_PREP") != nullptr;  // A/B switch
+  if (off) return MI_EINVAL;
+  CvtJobs side{};
+  side.j[0] = CvtJob{x, br, dx, nullptr, nullptr, 0, 0, nullptr, 0, 0, p.xtfb};
+  side.j[1] = CvtJob{y, b, dy, nullptr, nullptr, 0, 0, nullptr, 0, 0, p.ytfb};
+  side.j[2] = CvtJob{wg, dx, k, nullptr, nullptr, 0, 0, p.gfb};
+  side.j[3] = CvtJob{wh, dy, k, nullptr, nullptr, 0, 0, p.hfb};
+  side.dup = DupFlagJob{sid_rows, sid_cols, (int)(br / 32), (int)(b / 32), p.dup[0], p.dup[1], row_offset};
+  const PrepTSecond c{y, wh, b, k, dy, p.cb, p.cfb};
+  return launch_prep_t(x, wg, br, k, dx, p.ab, p.afb, side, st, "separable prep + A = X Wg | C = Y Wh", false, &c);
+}
+
 static int separable_flash(const int64_t* sid_rows, const int64_t* sid_cols, int64_t br, int64_t b, int64_t row_offset,
                            int64_t k, bool grad, const SeparablePlan& p, hipStream_t st) {
   FlashArgs a{};
@@ -1191,9 +1210,9 @@ int mi_separable_bwd(const float* x, const float* y, const float* wg, const floa
 
 }  // extern "C"
 
-/* One separable-critic step in ONE call (single GPU): prep, projections, the fused B x B kernel, then the two-launch tail
+/* One separable-critic step in ONE call (single GPU): prep + projections (one launch), the fused B x B kernel, then the two-launch tail
  * of the bilinear critic generalised to two products -- [records -> statistics and loss; partial sums -> dA, dC rows; dX =
- * dA Wg^T, dY = dC Wh^T on the matrix cores; dA^T, dC^T fragment-major] and [dWg = X^T dA | dWh = Y^T dC] -- five launches
+ * dA Wg^T, dY = dC Wh^T on the matrix cores; dA^T, dC^T fragment-major] and [dWg = X^T dA | dWh = Y^T dC] -- four launches
  * (round 3: eight, with a finalize, a slab-reduce and two split-K reduce launches).  Shapes outside the fused kernels: the
  * forward and the backward entry points, one after the other. */
 extern "C" int mi_separable_step(const float* x, const float* y, const float* wg, const float* wh, const int64_t* sid,
@@ -1215,7 +1234,8 @@ extern "C" int mi_separable_step(const float* x, const float* y, const float* wg
   }
   hipStream_t st = (hipStream_t)stream;
   if (p.fast && p.tail) {
-    rc = separable_prep_project(x, y, wg, wh, sid, sid, b, b, 0, d_img, d_txt, d_proj, p, st);
+    rc = separable_prep_project_fused(x, y, wg, wh, sid, sid, b, b, 0, d_img, d_txt, d_proj, p, st);
+    if (rc == MI_EINVAL) rc = separable_prep_project(x, y, wg, wh, sid, sid, b, b, 0, d_img, d_txt, d_proj, p, st);
     if (rc) return rc;
     rc = separable_flash(sid, sid, b, b, 0, d_proj, true, p, st);
     if (rc) return rc;

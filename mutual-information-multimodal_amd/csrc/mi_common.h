@@ -227,8 +227,11 @@ struct DynSmemCache {
 // (L / 8)-th workgroup of that XCD.  Work items that share operand panels get the same `outer` index and run back to
 // back on one XCD:  inner = (L / 8) % n_inner,  outer = (L % 8) + 8 * ((L / 8) / n_inner).
 // Launch 8 * n_inner * ceil(n_outer / 8) workgroups; returns false for the padding ones.
-__device__ __forceinline__ bool xcd_decode(int n_inner, int n_outer, int& inner, int& outer, int natural = 0) {
-  const int L = (int)blockIdx.x, e = L & 7, q = L >> 3;
+__device__ __forceinline__ bool xcd_decode(int n_inner, int n_outer, int& inner, int& outer, int natural = 0,
+                                           int lin = -1) {
+  // (lin >= 0: the linear id to decode instead of blockIdx.x -- a grid that holds several problems one after the other,
+  // each starting at a multiple of 8)
+  const int L = lin >= 0 ? lin : (int)blockIdx.x, e = L & 7, q = L >> 3;
   if (natural) {  // A/B switch: plain row-major order
     inner = L % n_inner;
     outer = L / n_inner;

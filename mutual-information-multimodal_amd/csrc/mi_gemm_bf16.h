@@ -1695,6 +1695,20 @@ struct PrepTArgs {
   int job_nx[4];     // 64-column tiles per tile row of job q
   CvtJobs jobs;
   int x_bf16;        // x points to bf16 data [m][k] (the bf16 boundary): the tile goes to LDS as it lies
+  // an optional SECOND product in the same launch (separable critic: A = X Wg and C = Y Wh): blocks [n_t, n_t + n_t2)
+  const float* x2;
+  const float* w2;
+  int64_t m2, n2, k2;
+  bf16_t* tb2;
+  bf16_t* tfb2;
+  int n_t2;
+};
+struct PrepTSecond {
+  const float* x;
+  const float* w;
+  int64_t m, n, k;
+  bf16_t* tb;
+  bf16_t* tfb;
 };
 constexpr int kPrepTLdB = 160;  // W image row pitch in bf16 elements (128 columns + 32 of padding = 320 bytes)
 constexpr size_t kPrepTSmem = (2 * kTile * kG2LD + 2 * kG2KT * kPrepTLdB) * sizeof(bf16_t);  // 77,824 bytes
@@ -1707,9 +1721,9 @@ static __global__ __launch_bounds__(256, 2) void bilinear_prep_t_kernel(PrepTArg
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   const int blk = (int)blockIdx.x;
   MI_STAMP(0);
-  if (blk >= a.n_t) {  // ---- conversion roles
+  if (blk >= a.n_t + a.n_t2) {  // ---- conversion roles
     float(*tile)[65] = reinterpret_cast<float(*)[65]>(smem_raw);
-    const int c = blk - a.n_t;
+    const int c = blk - a.n_t - a.n_t2;
     if (c >= a.job_begin[4]) {
       const DupFlagJob& D = a.jobs.dup;
       const int chunks = (D.nb + 63) / 64, w = c - a.job_begin[4];
@@ -1731,8 +1745,15 @@ static __global__ __launch_bounds__(256, 2) void bilinear_prep_t_kernel(PrepTArg
   bf16_t* Bs = As + 2 * kTile * kG2LD;               // [2][64 k][160]: W as it lies, n-contiguous; the B fragments come
                                                      // out K-major through ds_read_b64_tr_b16 (320-byte rows: the four
                                                      // rows of a transposed read fall on disjoint quarters of the banks)
+  // which product (the second one's blocks follow the first one's; both ranges are multiples of 8 long)
+  const bool second = blk >= a.n_t;
+  const float* const px = second ? a.x2 : a.x;
+  const float* const pw = second ? a.w2 : a.w;
+  const int64_t pm = second ? a.m2 : a.m, pn = second ? a.n2 : a.n, pk = second ? a.k2 : a.k;
+  bf16_t* const ptb = second ? a.tb2 : a.tb;
+  bf16_t* const ptfb = second ? a.tfb2 : a.tfb;
   int nb_, mb_;
-  if (!xcd_decode((int)(a.n / kTile), (int)((a.m + kTile - 1) / kTile), nb_, mb_)) return;
+  if (!xcd_decode((int)(pn / kTile), (int)((pm + kTile - 1) / kTile), nb_, mb_, 0, second ? blk - a.n_t : blk)) return;
   const int64_t m0 = (int64_t)mb_ * kTile, n0 = (int64_t)nb_ * kTile;
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63;
@@ -1758,11 +1779,11 @@ static __global__ __launch_bounds__(256, 2) void bilinear_prep_t_kernel(PrepTArg
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
       int64_t row = m0 + xr + 16 * q;
-      if (row >= a.m) row = a.m - 1;  // clamped rows only feed outputs the epilogue drops
-      xp[q] = a.x + row * a.k + 4 * xc;
+      if (row >= pm) row = pm - 1;  // clamped rows only feed outputs the epilogue drops
+      xp[q] = px + row * pk + 4 * xc;
     }
   }
-  const float* wp = a.w + (int64_t)wk * a.n + n0 + 4 * wc;
+  const float* wp = pw + (int64_t)wk * pn + n0 + 4 * wc;
   // bf16 x: a 128 x 64 tile is 1024 chunks of 16 bytes, four per thread: rows (tid >> 3) + 32 q, chunk tid & 7; they
   // travel in rx[0..3] as raw bits
   const bf16_t* xbp[4];
@@ -1771,8 +1792,8 @@ static __global__ __launch_bounds__(256, 2) void bilinear_prep_t_kernel(PrepTArg
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       int64_t row = m0 + br_ + 32 * q;
-      if (row >= a.m) row = a.m - 1;
-      xbp[q] = reinterpret_cast<const bf16_t*>(a.x) + row * a.k + 8 * bc_;
+      if (row >= pm) row = pm - 1;
+      xbp[q] = reinterpret_cast<const bf16_t*>(px) + row * pk + 8 * bc_;
     }
   }
   auto load_tile = [&](int64_t k0) {
@@ -1784,7 +1805,7 @@ static __global__ __launch_bounds__(256, 2) void bilinear_prep_t_kernel(PrepTArg
       for (int q = 0; q < 8; ++q) rx[q] = *reinterpret_cast<const f32x4*>(xp[q] + k0);
     }
 #pragma unroll
-    for (int q = 0; q < 8; ++q) rw[q] = *reinterpret_cast<const f32x4*>(wp + (k0 + 8 * q) * a.n);
+    for (int q = 0; q < 8; ++q) rw[q] = *reinterpret_cast<const f32x4*>(wp + (k0 + 8 * q) * pn);
   };
   auto store_tile = [&](int buf) {
     if constexpr (XB16) {
@@ -1804,7 +1825,7 @@ static __global__ __launch_bounds__(256, 2) void bilinear_prep_t_kernel(PrepTArg
     }
   };
 
-  const int nt = (int)(a.k / kG2KT);
+  const int nt = (int)(pk / kG2KT);
   load_tile(0);
   store_tile(0);
   __syncthreads();
@@ -1841,15 +1862,16 @@ static __global__ __launch_bounds__(256, 2) void bilinear_prep_t_kernel(PrepTArg
     if (t == 0) MI_STAMP(3);
   }
   MI_STAMP(4);
-  wave_tile_store_bf16(acc, smem_raw + wave * kEpiLdsPerWave, a.tb, a.n, nullptr, 0, m0 + wm * 64, n0 + wn * 64, a.m, a.n,
-                       a.tfb);
+  wave_tile_store_bf16(acc, smem_raw + wave * kEpiLdsPerWave, ptb, pn, nullptr, 0, m0 + wm * 64, n0 + wn * 64, pm, pn,
+                       ptfb);
   MI_STAMP(5);
 }
 
 // conversions: up to four CvtJob (64 x 64 tiles each) + the flag job; returns MI_EINVAL for shapes the fused kernel does
 // not take (the caller then runs the conversion launch and the plain GEMM)
 static inline int launch_prep_t(const float* x, const float* w, int64_t m, int64_t n, int64_t k, bf16_t* tb, bf16_t* tfb,
-                                const CvtJobs& jobs, hipStream_t st, const char* what, bool x_bf16 = false) {
+                                const CvtJobs& jobs, hipStream_t st, const char* what, bool x_bf16 = false,
+                                const PrepTSecond* second = nullptr) {
   static const bool off = getenv("MI_NO_PREP_T") != nullptr;  // A/B switch: separate conversion and GEMM launches
   if (off || k % 64 != 0 || n % kTile != 0 || m < 1 || (uintptr_t)x % 16 != 0 || (uintptr_t)w % 16 != 0 ||
       (uintptr_t)tb % 16 != 0 || (tfb && (m % 32 != 0 || (uintptr_t)tfb % 16 != 0)))
@@ -1858,6 +1880,14 @@ static inline int launch_prep_t(const float* x, const float* w, int64_t m, int64
   a.x = x; a.w = w; a.m = m; a.n = n; a.k = k; a.tb = tb; a.tfb = tfb;
   a.x_bf16 = x_bf16 ? 1 : 0;
   a.n_t = (int)(8 * (n / kTile) * (((m + kTile - 1) / kTile + 7) / 8));  // padded for the XCD mapping
+  if (second) {
+    const PrepTSecond& q = *second;
+    if (x_bf16 || q.k % 64 != 0 || q.n % kTile != 0 || q.m < 1 || (uintptr_t)q.x % 16 != 0 || (uintptr_t)q.w % 16 != 0 ||
+        (uintptr_t)q.tb % 16 != 0 || (q.tfb && (q.m % 32 != 0 || (uintptr_t)q.tfb % 16 != 0)))
+      return MI_EINVAL;
+    a.x2 = q.x; a.w2 = q.w; a.m2 = q.m; a.n2 = q.n; a.k2 = q.k; a.tb2 = q.tb; a.tfb2 = q.tfb;
+    a.n_t2 = (int)(8 * (q.n / kTile) * (((q.m + kTile - 1) / kTile + 7) / 8));
+  }
   a.jobs = jobs;
   int total = 0;
   for (int q = 0; q < 4; ++q) {
@@ -1879,11 +1909,11 @@ static inline int launch_prep_t(const float* x, const float* w, int64_t m, int64
   if (x_bf16) {
     MI_SET_DYN_SMEM(bilinear_prep_t_kernel<true>, kPrepTSmem, "hipFuncSetAttribute(bilinear_prep_t_kernel)");
     ProfScope prof_(what, st);
-    hipLaunchKernelGGL(bilinear_prep_t_kernel<true>, dim3((unsigned)(a.n_t + total)), dim3(256), kPrepTSmem, st, a);
+    hipLaunchKernelGGL(bilinear_prep_t_kernel<true>, dim3((unsigned)(a.n_t + a.n_t2 + total)), dim3(256), kPrepTSmem, st, a);
   } else {
     MI_SET_DYN_SMEM(bilinear_prep_t_kernel<false>, kPrepTSmem, "hipFuncSetAttribute(bilinear_prep_t_kernel)");
     ProfScope prof_(what, st);
-    hipLaunchKernelGGL(bilinear_prep_t_kernel<false>, dim3((unsigned)(a.n_t + total)), dim3(256), kPrepTSmem, st, a);
+    hipLaunchKernelGGL(bilinear_prep_t_kernel<false>, dim3((unsigned)(a.n_t + a.n_t2 + total)), dim3(256), kPrepTSmem, st, a);
   }
   MI_LAUNCH_CHECK(what);
   return MI_OK;

@@ -133,29 +133,3 @@ def test_path_queries(lib, caplog):
         assert _hip.note_path("bilinear", (4096, 4096, 512, 512), _hip.MI_PREC_BF16) == _hip.MI_PATH_FUSED_TAIL
     assert sum("outside the fused" in r.getMessage() for r in caplog.records) == 1
 
-
-def test_host_side_under_asan(tmp_path):
-    """The HOST side of the C-ABI (argument / shape / enum / workspace checks, the planners, the error strings) under
-    AddressSanitizer: `make ASAN=1` builds the library's host code instrumented (device code as usual: GPU ASan is not
-    available on the pool), tests/asan_host_driver.cpp sweeps the queries over valid, ragged and degenerate shapes and
-    calls every entry point with arguments it has to refuse.  No GPU is touched.  (First run: the sweep found a division
-    by zero in the workspace planner for a zero-width critic; the queries now return 0 for non-positive sizes.)"""
-    import shutil
-    import subprocess
-    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    if not os.path.exists(hipcc):
-        pytest.skip("no hipcc")
-    csrc = os.path.join(ROOT, "mutual-information-multimodal_amd", "csrc")
-    r = subprocess.run(["make", "-C", csrc, "ASAN=1", "-j4"], capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    libdir = os.path.join(ROOT, "mutual-information-multimodal_amd", "lib_asan")
-    exe = str(tmp_path / "asan_host_driver")
-    r = subprocess.run([hipcc, "-O1", "-g", "-std=c++17", "-fsanitize=address", "-fno-omit-frame-pointer",
-                        "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "asan_host_driver.cpp"),
-                        "-L" + libdir, "-lmi_critic_hip", "-Wl,-rpath," + libdir, "-o", exe],
-                       capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0, r.stderr[-2000:]
-    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0:abort_on_error=0")
-    r = subprocess.run([exe], capture_output=True, text=True, timeout=300, env=env)
-    assert r.returncode == 0 and "asan driver ok" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
-    assert "AddressSanitizer" not in r.stderr

@@ -1,4 +1,4 @@
-// Host side of the C-ABI under AddressSanitizer (tests/test_abi.py::test_host_side_under_asan; library: make ASAN=1).
+// Host side of the C-ABI under AddressSanitizer (tests/test_asan_host.py; built by tools/asan_host/build_and_run.sh).
 // No GPU is needed or touched: every call below must return from the host-side argument / shape / workspace checks --
 // the code that runs on every call of the product and that a GPU sanitizer build (not available on the pool) would not
 // cover any better.  Prints one line per section and "asan driver ok" at the end; any ASan report aborts the process.
