@@ -172,6 +172,16 @@ static int fast_prep_and_t(const float* x, const float* y, const float* w, const
     if (rc1 != MI_EINVAL) return rc1;
   }
   const int x3 = p.x3;
+  // G-materialising path in plain bf16 (widths outside the fused kernel, e.g. the reference's 768): the same single
+  // launch -- T tiles (row-major and transposed) beside the conversions.  MI_NO_PREP_T=1: the two launches below.
+  if (!p.fl.ok && x3 == 1 && part == 0) {
+    CvtJobs side{};
+    side.j[0] = CvtJob{x, br, dx, nullptr, p.xtb, 0, 0, nullptr, 0, 0, p.xtfb};
+    side.j[1] = CvtJob{y, b, dy, p.yb, p.ytb};
+    side.j[2] = CvtJob{w, dx, dy, p.wb, p.wtb, 0, 0, p.wfb};
+    const int rc1 = launch_prep_t(x, w, br, dy, dx, p.tb, nullptr, side, st, "bilinear prep + T = X W", false, nullptr, p.ttb);
+    if (rc1 != MI_EINVAL) return rc1;
+  }
   const int ra = x3 == 3 ? 1 : 0, rb = x3 == 3 ? 2 : 0;  // bf16x3 roles of A-side and B-side operands
   CvtJobs jobs{};
   jobs.j[0] = CvtJob{x, br, dx, p.xb, p.xtb, 0, 0, nullptr, ra, ra, p.xtfb};

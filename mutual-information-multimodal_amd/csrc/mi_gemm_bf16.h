@@ -1690,6 +1690,7 @@ struct PrepTArgs {
   int64_t m, n, k;   // k % 64 == 0, n % 128 == 0
   bf16_t* tb;        // [m][n]
   bf16_t* tfb;       // fragment-major copy (EpiOut::bf_frag) or null
+  bf16_t* ttb;       // T^T [n][m] or null (the G-materialising path reads it as the B operand of dY = G^T T; m % 8 == 0)
   int n_t;           // blocks of the T role (tiles, padded to 8 x tiles-per-panel x ceil(panels / 8))
   int job_begin[6];  // conversion blocks (counted from n_t): first block of job q; [4] = flags, [5] = end
   int job_nx[4];     // 64-column tiles per tile row of job q
@@ -1862,8 +1863,8 @@ static __global__ __launch_bounds__(256, 2) void bilinear_prep_t_kernel(PrepTArg
     if (t == 0) MI_STAMP(3);
   }
   MI_STAMP(4);
-  wave_tile_store_bf16(acc, smem_raw + wave * kEpiLdsPerWave, ptb, pn, nullptr, 0, m0 + wm * 64, n0 + wn * 64, pm, pn,
-                       ptfb);
+  wave_tile_store_bf16(acc, smem_raw + wave * kEpiLdsPerWave, ptb, pn, second ? nullptr : a.ttb, pm, m0 + wm * 64,
+                       n0 + wn * 64, pm, pn, ptfb);
   MI_STAMP(5);
 }
 
@@ -1871,7 +1872,7 @@ static __global__ __launch_bounds__(256, 2) void bilinear_prep_t_kernel(PrepTArg
 // not take (the caller then runs the conversion launch and the plain GEMM)
 static inline int launch_prep_t(const float* x, const float* w, int64_t m, int64_t n, int64_t k, bf16_t* tb, bf16_t* tfb,
                                 const CvtJobs& jobs, hipStream_t st, const char* what, bool x_bf16 = false,
-                                const PrepTSecond* second = nullptr) {
+                                const PrepTSecond* second = nullptr, bf16_t* ttb = nullptr) {
   static const bool off = getenv("MI_NO_PREP_T") != nullptr;  // A/B switch: separate conversion and GEMM launches
   if (off || k % 64 != 0 || n % kTile != 0 || m < 1 || (uintptr_t)x % 16 != 0 || (uintptr_t)w % 16 != 0 ||
       (uintptr_t)tb % 16 != 0 || (tfb && (m % 32 != 0 || (uintptr_t)tfb % 16 != 0)))
@@ -1879,6 +1880,8 @@ static inline int launch_prep_t(const float* x, const float* w, int64_t m, int64
   PrepTArgs a{};
   a.x = x; a.w = w; a.m = m; a.n = n; a.k = k; a.tb = tb; a.tfb = tfb;
   a.x_bf16 = x_bf16 ? 1 : 0;
+  if (ttb && (m % 8 != 0 || (uintptr_t)ttb % 16 != 0)) return MI_EINVAL;
+  a.ttb = ttb;
   a.n_t = (int)(8 * (n / kTile) * (((m + kTile - 1) / kTile + 7) / 8));  // padded for the XCD mapping
   if (second) {
     const PrepTSecond& q = *second;
