@@ -490,9 +490,15 @@ class GlobalBatchGraphStep:
     ``grad_params`` (overwritten by every step)."""
 
     def __init__(self, x, y, sid, params: Sequence[torch.Tensor], estimator: str = "infonce", precision: str = "bf16",
-                 critic: str = "bilinear", group=None, ops=None, capture: bool = True):
+                 critic: str = "bilinear", group=None, ops=None, capture: bool = True, overlap_reduce_scatter=None):
         from .mi_critics import _estimator_code, _precision_code
         self.group = group
+        # step_eager(): start the reduce-scatter of dY between the backward's two launches (it then runs beside dW).  OFF by
+        # default: with direct calls the step is bound by the HOST (one-rank RCCL rehearsal, B = 4096: 0.196 ms per step
+        # for 0.12 ms of kernels), and the extra C call + async handle cost 13 us there (0.208 ms) -- a GPU-side overlap
+        # buys nothing until the host keeps ahead.  MI_DIST_RS_OVERLAP=1 or the argument turn it on.
+        self.overlap_reduce_scatter = (bool(os.environ.get("MI_DIST_RS_OVERLAP")) if overlap_reduce_scatter is None
+                                       else bool(overlap_reduce_scatter))
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
         self.ops = ops if ops is not None else {"bilinear": HipBilinearOps, "separable": HipSeparableOps, "concat_mlp": HipConcatMlpOps}[critic]()
@@ -683,10 +689,10 @@ class GlobalBatchGraphStep:
         self._gather_inputs()
         self._forward()
         self._gather_records()
-        if self._raw and hasattr(self.ops, "merge_backward_tail") and not os.environ.get("MI_DIST_NO_RS_OVERLAP"):
+        if self._raw and hasattr(self.ops, "merge_backward_tail") and self.overlap_reduce_scatter:
             # the reduce-scatter of dY needs the backward's FIRST launch only: started (on the backend's stream) before the
             # dW launch, it runs beside it; the parameter all-reduce follows dW.  Same five collectives, same order on
-            # every rank.  (MI_DIST_NO_RS_OVERLAP=1: A/B switch.)
+            # every rank.
             got = self.ops.merge_backward_tail(self.saved, self.records_raw, self.world * self.x.shape[0], self.est,
                                                self.grad_out, out=self._out)
             self.loss, self.stats = got[0], got[1]

@@ -75,6 +75,10 @@ def main():
                                         critic=kind)
         l1 = step.step_eager().clone()
         check("step_eager", l1, step.grad_x, step.grad_y, step.grad_params)
+        step.overlap_reduce_scatter = True   # the split backward: dY's reduce-scatter started before the dW launch
+        l1b = step.step_eager().clone()
+        check("step_eager, reduce-scatter beside dW", l1b, step.grad_x, step.grad_y, step.grad_params)
+        step.overlap_reduce_scatter = False
         l2 = step.step().clone()
         check("step (replay)", l2, step.grad_x, step.grad_y, step.grad_params)
         l3 = step.step().clone()

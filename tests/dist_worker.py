@@ -350,7 +350,8 @@ def run_raw(rank, world, port, b_local, d, estimator, out_dir, split_tail=False)
             return start(t, group)
         dmod._reduce_scatter_rows_start = logged
     st = GlobalBatchGraphStep(x[sl].contiguous(), y[sl].contiguous(), codes[sl].contiguous(), [w.clone()], estimator, "f32",
-                              critic="bilinear", group=dist.group.WORLD, ops=ops, capture=False)
+                              critic="bilinear", group=dist.group.WORLD, ops=ops, capture=False,
+                              overlap_reduce_scatter=split_tail)
     st.step()
     loss = st.step()
     torch.save({"loss": loss.detach().reshape(-1), "dx": st.grad_x, "dy": st.grad_y, "dparams": [g.clone() for g in st.grad_params],
