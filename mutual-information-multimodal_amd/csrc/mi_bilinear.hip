@@ -791,8 +791,7 @@ int mi_bilinear_fp8_stage(const float* x, const float* y, const float* w, int64_
   hipStream_t st = (hipStream_t)stream;
   // non-negative floats and their bit patterns order alike: the absmax slots hold bit patterns, amax_io floats
   auto copy = [&](void* dst, const void* src, size_t n) {
-    const hipError_t e = hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToDevice, st);
-    return e == hipSuccess ? MI_OK : hip_fail(e, "hipMemcpyAsync(fp8 absmax)");
+    return launch_copy_words(dst, src, n, st, "copy_words_kernel(fp8 absmax)");
   };
   if (stage == 0) {
     rc = fp8_stage0(x, y, w, b_rows, b, d_img, d_txt, p, st);

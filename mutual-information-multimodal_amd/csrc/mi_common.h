@@ -57,6 +57,15 @@ static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; 
 static __global__ void zero_words_kernel(unsigned* p, int n) {
   for (int e = threadIdx.x; e < n; e += 64) p[e] = 0u;
 }
+// ... and the same for small device-to-device copies (statistics words, counters): kernels, not memcpy nodes
+static __global__ void copy_words_kernel(unsigned* dst, const unsigned* src, int n) {
+  for (int e = threadIdx.x; e < n; e += 64) dst[e] = src[e];
+}
+static inline int launch_copy_words(void* dst, const void* src, size_t bytes, hipStream_t st, const char* what) {
+  hipLaunchKernelGGL(copy_words_kernel, dim3(1), dim3(64), 0, st, (unsigned*)dst, (const unsigned*)src, (int)(bytes / 4));
+  const hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : hip_fail(e, what);
+}
 static inline int launch_zero_words(void* p, size_t bytes, hipStream_t st, const char* what) {
   hipLaunchKernelGGL(zero_words_kernel, dim3(1), dim3(64), 0, st, (unsigned*)p, (int)(bytes / 4));
   const hipError_t e = hipGetLastError();

@@ -260,8 +260,8 @@ int mi_pair_index(const int64_t* sid, int64_t b, int32_t* pair_i, int32_t* pair_
     MI_LAUNCH_CHECK("pairs_emit_kernel");
   }
   if (n_rows_dev) {
-    hipError_t e = hipMemcpyAsync(n_rows_dev, nrows, sizeof(int64_t), hipMemcpyDeviceToDevice, st);
-    if (e != hipSuccess) return hip_fail(e, "hipMemcpyAsync(n_rows_dev)");
+    const int rc = launch_copy_words(n_rows_dev, nrows, sizeof(int64_t), st, "copy_words_kernel(n_rows_dev)");
+    if (rc) return rc;
   }
   return MI_OK;
 }
