@@ -13,7 +13,11 @@ AdamW as published there (``correct_bias=False`` is what the reference passes, a
 
 Defaults: betas (0.9, 0.999), eps 1e-6 (not torch's 1e-8), weight_decay 0.  This differs from ``torch.optim.AdamW``
 (always bias-corrected, decay applied before the update), so it is written out here.  Host-side bookkeeping on a few
-hundred small tensors: plain torch ops on the parameters' device, nothing for a HIP kernel to win."""
+hundred small tensors: plain torch ops on the parameters' device, nothing for a HIP kernel to win.
+
+Upstream notice (pytorch-transformers 1.0.0, ``optimization.py``): Copyright 2018 The Google AI Language Team Authors and
+The HuggingFace Inc. team.  Licensed under the Apache License, Version 2.0 (http://www.apache.org/licenses/LICENSE-2.0);
+the interface (class names, argument names, defaults) and the update rule restated here follow that file."""
 from __future__ import annotations
 
 import math
