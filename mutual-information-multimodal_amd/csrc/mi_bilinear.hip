@@ -53,8 +53,29 @@ struct BilinearPlan {
   // bf16 copies of the quantised values for the backward live in xtb, ytb, wb, ttb
   fp8_t *qx8, *qy8, *qwt8, *qt8;
   Fp8Scales* f8sc;
+  // exact-fp32 path (MI_PREC_F32): split-K slabs of the products whose output has too few 128 x 128 tiles to fill the chip
+  float* gen_slab;
+  int64_t gen_slab_floats;
   size_t bytes;
 };
+
+// Split-K of a generic-path product: with fewer than 192 output tiles the launch leaves CUs idle (dW = X^T dT at d = 512 is
+// 16 tiles with K = B: 567 us for 2 GFLOP at B = 4096).  Splits fill ~256 workgroups, K chunks are multiples of 64.
+static void generic_splitk(int64_t m, int64_t n, int64_t k, int& splits, int64_t& kchunk) {
+  const int64_t tiles = ((m + kTile - 1) / kTile) * ((n + kTile - 1) / kTile);
+  int64_t sp = tiles >= 192 ? 1 : (256 + tiles - 1) / tiles;
+  if (sp > 16) sp = 16;
+  kchunk = (k + sp - 1) / sp;
+  kchunk = (kchunk + 63) / 64 * 64;
+  sp = kchunk > 0 ? (k + kchunk - 1) / kchunk : 1;
+  splits = (int)(sp < 1 ? 1 : sp);
+}
+static int64_t generic_slab_floats(int64_t m, int64_t n, int64_t k) {
+  int sp;
+  int64_t kc;
+  generic_splitk(m, n, k, sp, kc);
+  return sp > 1 ? (int64_t)sp * m * n : 0;
+}
 
 static bool fp8_ok(int64_t br, int64_t b, int64_t dx, int64_t dy, int precision, bool has_w) {
   return precision == MI_PREC_FP8 && has_w && br % 8 == 0 && b % 8 == 0 && dx % 16 == 0 && dy % 16 == 0;
@@ -130,6 +151,17 @@ static BilinearPlan plan_bilinear(Workspace& ws, int64_t br, int64_t b, int64_t 
     p.dt_splits = (int)sp;
     p.dt_kchunk = kc;
     p.dt_slab = sp > 1 ? ws.take<float>(sp * br * dy) : nullptr;
+  }
+  if (precision == MI_PREC_F32) {
+    int64_t need = generic_slab_floats(br, dy, dx);                      // T = X W
+    const int64_t cand[3] = {generic_slab_floats(br, dy, b),             // dT = G Y
+                             generic_slab_floats(b, dy, br),             // dY = G^T T
+                             generic_slab_floats(dx, dy, br)};           // dW = X^T dT
+    for (int64_t c : cand) need = c > need ? c : need;
+    const int64_t c4 = generic_slab_floats(br, dx, dy);                  // dX = dT W^T
+    need = c4 > need ? c4 : need;
+    p.gen_slab_floats = need;
+    p.gen_slab = need > 0 ? ws.take<float>(need) : nullptr;
   }
   p.bytes = ws.off;
   return p;
@@ -517,6 +549,24 @@ static int bilinear_bwd_fp8(const int64_t* sid_rows, const int64_t* sid_cols, in
 }
 
 // ------------------------------------------------------------------------------------------------ generic path
+// out [M][N] (ld) = A B^T with K split into slabs when the output has too few tiles (exact-fp32 mode only: the plan holds
+// the slab buffer); the slabs are added in split order (fixed order: reproducible)
+template <typename OpT, typename TA, typename TB>
+static int generic_gemm_store(const Operand<TA>& A, const Operand<TB>& B, int64_t M, int64_t N, int64_t K, float* out,
+                              int64_t ld, const BilinearPlan& p, hipStream_t st, const char* what) {
+  int sp = 1;
+  int64_t kc = K;
+  static const bool off = getenv("MI_GENERIC_NO_SPLITK") != nullptr;  // A/B switch
+  if (p.gen_slab && !off) generic_splitk(M, N, K, sp, kc);
+  if (sp <= 1 || (int64_t)sp * M * N > p.gen_slab_floats)
+    return launch_gemm<OpT>(A, B, M, N, K, EpiStore{out, ld, nullptr, 1.0f, 0}, st, what);
+  EpiStore e{p.gen_slab, N, nullptr, 1.0f, 0};
+  e.slab_stride = M * N;
+  const int rc = launch_gemm<OpT>(A, B, M, N, K, e, st, what, sp, kc);
+  if (rc) return rc;
+  return launch_slab_reduce_ld(p.gen_slab, sp, M, N, out, ld, st, "slab_reduce_ld_kernel");
+}
+
 template <typename OpT>
 static int bilinear_fwd_impl(const float* x, const float* y, const float* w, const int64_t* sid_rows,
                              const int64_t* sid_cols, int64_t br, int64_t b, int64_t row_offset, int64_t dx, int64_t dy,
@@ -525,8 +575,8 @@ static int bilinear_fwd_impl(const float* x, const float* y, const float* w, con
   int rc = MI_OK;
   const float* t = x;  // w == nullptr: separable form, the caller passes the projected embeddings (d_img == d_txt)
   if (w) {
-    rc = launch_gemm<OpT>(make_operand(x, dx, 1), make_operand(w, 1, dy), br, dy, dx,
-                          EpiStore{p.t, dy, nullptr, 1.0f, 0}, st, "bilinear T = X W (generic)");
+    rc = generic_gemm_store<OpT>(make_operand(x, dx, 1), make_operand(w, 1, dy), br, dy, dx, p.t, dy, p, st,
+                                 "bilinear T = X W (generic)");
     if (rc) return rc;
     t = p.t;
   }
@@ -547,8 +597,8 @@ static int bilinear_bwd_impl(const float* x, const float* y, const float* w, con
   const float* t = x;
   float* dt = grad_x;  // w == nullptr: dT is dX
   if (w) {
-    rc = launch_gemm<OpT>(make_operand(x, dx, 1), make_operand(w, 1, dy), br, dy, dx,
-                          EpiStore{p.t, dy, nullptr, 1.0f, 0}, st, "bilinear T = X W (generic, bwd)");
+    rc = generic_gemm_store<OpT>(make_operand(x, dx, 1), make_operand(w, 1, dy), br, dy, dx, p.t, dy, p, st,
+                                 "bilinear T = X W (generic, bwd)");
     if (rc) return rc;
     t = p.t;
     dt = p.dt;
@@ -556,18 +606,18 @@ static int bilinear_bwd_impl(const float* x, const float* y, const float* w, con
   rc = launch_gemm<OpT>(make_operand(t, dy, 1), make_operand(y, dy, 1), br, b, dy,
                         EpiGradScore<TG>{sid_rows, sid_cols, row_offset, stats, grad_out, g}, st, "bilinear G (generic)");
   if (rc) return rc;
-  rc = launch_gemm<OpT>(make_operand((const TG*)g, b, 1), make_operand(y, 1, dy), br, dy, b,
-                        EpiStore{dt, dy, nullptr, 1.0f, 0}, st, "bilinear dT = G Y (generic)");
+  rc = generic_gemm_store<OpT>(make_operand((const TG*)g, b, 1), make_operand(y, 1, dy), br, dy, b, dt, dy, p, st,
+                               "bilinear dT = G Y (generic)");
   if (rc) return rc;
-  rc = launch_gemm<OpT>(make_operand((const TG*)g, 1, b), make_operand(t, 1, dy), b, dy, br,
-                        EpiStore{grad_y, dy, nullptr, 1.0f, 0}, st, "bilinear dY = G^T T (generic)");
+  rc = generic_gemm_store<OpT>(make_operand((const TG*)g, 1, b), make_operand(t, 1, dy), b, dy, br, grad_y, dy, p, st,
+                               "bilinear dY = G^T T (generic)");
   if (rc) return rc;
   if (!w) return MI_OK;
-  rc = launch_gemm<OpT>(make_operand(x, 1, dx), make_operand((const float*)p.dt, 1, dy), dx, dy, br,
-                        EpiStore{grad_w, dy, nullptr, 1.0f, 0}, st, "bilinear dW = X^T dT (generic)");
+  rc = generic_gemm_store<OpT>(make_operand(x, 1, dx), make_operand((const float*)p.dt, 1, dy), dx, dy, br, grad_w, dy, p, st,
+                               "bilinear dW = X^T dT (generic)");
   if (rc) return rc;
-  return launch_gemm<OpT>(make_operand((const float*)p.dt, dy, 1), make_operand(w, dy, 1), br, dx, dy,
-                          EpiStore{grad_x, dx, nullptr, 1.0f, 0}, st, "bilinear dX = dT W^T (generic)");
+  return generic_gemm_store<OpT>(make_operand((const float*)p.dt, dy, 1), make_operand(w, dy, 1), br, dx, dy, grad_x, dx, p,
+                                 st, "bilinear dX = dT W^T (generic)");
 }
 
 static int check_common(const char* fn, int64_t br, int64_t b, int64_t row_offset, int64_t dx, int64_t dy,
