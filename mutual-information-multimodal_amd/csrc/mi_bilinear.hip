@@ -133,7 +133,9 @@ static BilinearPlan plan_bilinear(Workspace& ws, int64_t br, int64_t b, int64_t 
   int64_t tiles = ((dx + kTile - 1) / kTile) * ((dy + kTile - 1) / kTile);
   // split-K so that dW brings ~128 workgroups to the launch it shares with dX (measured at B = 4096, d = 512: 8 splits
   // 16.7 us, 16 splits 19.0 us, 4 splits 19.8 us for the pair)
-  int64_t splits = (128 + tiles - 1) / tiles;
+  // (the fp8 mode launches dW on its own: 256 workgroups there -- 44 -> 2x fewer idle CUs at d = 1024)
+  const int64_t dw_target = precision == MI_PREC_FP8 ? 256 : 128;
+  int64_t splits = (dw_target + tiles - 1) / tiles;
   if (const char* e = getenv("MI_DW_SPLITS")) splits = atoi(e) > 0 ? atoi(e) : splits;  // A/B switch
   int64_t kchunk = (br + splits - 1) / splits;
   kchunk = (kchunk + kG2KT - 1) / kG2KT * kG2KT;

@@ -1348,7 +1348,8 @@ static inline int launch_gemm_bf16(const GemmBf16Args& args_in, int n_splits, co
     static const bool no_p256 = getenv("MI_GEMM_NO_P256") != nullptr;
     const int64_t t128 = ((mm + 127) / 128) * ((nn + 127) / 128) * args.n_problems;
     const int64_t t256 = ((mm + 255) / 256) * ((nn + 127) / 128) * args.n_problems;
-    if (!big2 && !no_p256 && dma_ok && n_splits == 1 && args.p[0].k >= 2048 && !gemm_old_kernels() && t128 > 256 &&
+    static const int64_t p256_min_k = getenv("MI_GEMM_P256_MINK") ? atoll(getenv("MI_GEMM_P256_MINK")) : 2048;  // A/B
+    if (!big2 && !no_p256 && dma_ok && n_splits == 1 && args.p[0].k >= p256_min_k && !gemm_old_kernels() && t128 > 256 &&
         t256 <= 256 && t256 >= 160 && !(args.n_problems == 1 && gemm_bf16_use_big(mm, nn, args.p[0].k))) {
       MI_SET_DYN_SMEM((gemm_bf16_pipe_kernel<PipeCfg256x128, Epi>), PipeCfg256x128::SMEM,
                       "hipFuncSetAttribute(gemm_bf16_pipe_kernel 256x128)");
