@@ -635,20 +635,29 @@ __global__ __launch_bounds__(256) void concat_bwd_finish_w2_kernel(const float* 
     dW2[(int64_t)n * H1 + k] = w3n * d;
     dot += w2[(int64_t)n * H1 + k] * d;
   }
+  // the row-slice sums of the db2 kernel (up to 1,024 of them): thread t adds slices t, t + 256, ..., then the fixed block
+  // reduction below.  (One thread walking all of them -- 1,024 dependent strided loads per workgroup -- was most of this
+  // kernel's 0.3 ms.)
+  float mp = 0.0f, gp = 0.0f;
+  for (int s = tid; s < n_msplit; s += 256) mp += mslab[(int64_t)s * H2 + n];
+  if (n == 0)
+    for (int s = tid; s < n_msplit; s += 256) gp += gsum[s];
   dot = wave_sum(dot);
-  if ((tid & 63) == 0) red[tid >> 6] = dot;
+  mp = wave_sum(mp);
+  gp = wave_sum(gp);
+  __shared__ float redm[4], redg[4];
+  if ((tid & 63) == 0) {
+    red[tid >> 6] = dot;
+    redm[tid >> 6] = mp;
+    redg[tid >> 6] = gp;
+  }
   __syncthreads();
   if (tid == 0) {
     const float total = (red[0] + red[1]) + (red[2] + red[3]);
-    float m = 0.0f;
-    for (int s = 0; s < n_msplit; ++s) m += mslab[(int64_t)s * H2 + n];
+    const float m = (redm[0] + redm[1]) + (redm[2] + redm[3]);
     dW3[n] = total + b2[n] * m;
     db2[n] = w3n * m;
-    if (n == 0) {
-      float g = 0.0f;
-      for (int s = 0; s < n_msplit; ++s) g += gsum[s];
-      db3[0] = g;
-    }
+    if (n == 0) db3[0] = (redg[0] + redg[1]) + (redg[2] + redg[3]);
   }
 }
 
