@@ -303,9 +303,18 @@ static int concat_bwd_impl(const float* x, const float* y, const float* w1, cons
                          h2, p.rows_per_dsplit, xcd_natural(), p.d_slab);
     }
     MI_LAUNCH_CHECK("concat_bwd_dw2_kernel");
-    const size_t smem2 = (size_t)((b + 31) / 32) * 32 * sizeof(float);
-    MI_SET_DYN_SMEM((concat_bwd_db2_kernel), smem2, "hipFuncSetAttribute(concat_bwd_db2_kernel)");
-    {
+    static const bool db2_old = getenv("MI_DB2_OLD") != nullptr;  // A/B switch: the bit-by-bit kernel in the fp16 mode too
+    if (kF16 && !X3 && !db2_old) {
+      // fp16 mode: g' as an fp16 operand, two bits per v_dot2c_f32_f16 (mi_concat_f16.h)
+      const size_t smem2 = 256 * 16 + (size_t)((b + 31) / 32) * 32 * sizeof(f16_t);
+      MI_SET_DYN_SMEM((concat_bwd_db2_f16_kernel), smem2, "hipFuncSetAttribute(concat_bwd_db2_f16_kernel)");
+      ProfScope prof_("concat_bwd_db2_kernel", st);
+      hipLaunchKernelGGL(concat_bwd_db2_f16_kernel, dim3((unsigned)p.n_msplit), dim3(512), smem2, st,
+                         (const unsigned*)p.bitsN, scores, sid_rows, sid_cols, stats, grad_out, br, b, row_offset, h2,
+                         p.rows_per_msplit, p.m_slab, p.g_sum);
+    } else {
+      const size_t smem2 = (size_t)((b + 31) / 32) * 32 * sizeof(float);
+      MI_SET_DYN_SMEM((concat_bwd_db2_kernel), smem2, "hipFuncSetAttribute(concat_bwd_db2_kernel)");
       ProfScope prof_("concat_bwd_db2_kernel", st);
       hipLaunchKernelGGL(concat_bwd_db2_kernel, dim3((unsigned)p.n_msplit), dim3(512), smem2, st,
                          (const unsigned*)p.bitsN, scores, sid_rows, sid_cols, stats, grad_out, br, b, row_offset, h2,

@@ -701,6 +701,88 @@ __global__ __launch_bounds__(512) void concat_bwd_dw2_f16_kernel(
 
 namespace mi {
 
+// ================================================================================================= db2, fp16 mode
+// concat_bwd_db2_kernel (mi_concat_bwd.h) walks the 32 bits of every sign word with ~3 vector instructions per bit
+// (0.85 ms at B = 4096 for 2 MB of output).  In the fp16 mode g is an fp16 operand anyway (the dW2 kernel multiplies
+// g' = g s_g into its generated operand): here a byte of the word selects eight 0 / 1 halves from a table and
+// v_dot2c_f32_f16 adds two products g' * bit per instruction into an fp32 sum -- 4 table reads + 4 reads of g' + 16 dots per
+// word.  Same outputs (row-slice sums of g M per hidden unit, the slice's sum of g for db3).  The sums come out scaled by
+// s_g and without grad_out, both applied to the finished sum.
+__global__ __launch_bounds__(512) void concat_bwd_db2_f16_kernel(const unsigned* __restrict__ bitsN, const float* __restrict__ S,
+                                                                 const int64_t* __restrict__ sid_rows,
+                                                                 const int64_t* __restrict__ sid_cols,
+                                                                 const mi_stats* __restrict__ stats,
+                                                                 const float* __restrict__ grad_out, int64_t b_rows,
+                                                                 int64_t b, int64_t row_offset, int H2, int rows_per_split,
+                                                                 float* __restrict__ mslab /* [n_split][H2] */,
+                                                                 float* __restrict__ gsum /* [n_split] */) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  typedef _Float16 f16x8v __attribute__((ext_vector_type(8)));
+  f16x8v* lut = reinterpret_cast<f16x8v*>(smem_raw);                     // [256]: bit q of the index -> half q = 1
+  f16_t* grow = reinterpret_cast<f16_t*>(smem_raw + 256 * 16);          // [32 * JB]: g' of the row, zero beyond the batch
+  __shared__ float red[8];
+  const int tid = threadIdx.x;
+  const int64_t JB = (b + 31) / 32;
+  const int64_t ilo = (int64_t)blockIdx.x * rows_per_split;
+  int64_t ihi = ilo + rows_per_split;
+  if (ihi > b_rows) ihi = b_rows;
+  const float go = grad_out ? grad_out[0] : 1.0f;
+  const float lse = stats->lse;
+  const float gpos = -1.0f / (float)stats->n_pos;
+  const float gscale = f16_g_scale(stats, kF16GLo);
+  if (tid < 256) {
+    f16x8v f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) f[q] = (f16_t)(((tid >> q) & 1) ? 1.0f : 0.0f);
+    lut[tid] = f;
+  }
+  float gtot = 0.0f;
+  float macc[2] = {0.0f, 0.0f};  // hidden units tid and tid + 512
+  for (int64_t li = ilo; li < ihi; ++li) {
+    __syncthreads();
+    const int64_t si = sid_rows[li];
+    for (int64_t gj = tid; gj < JB * 32; gj += 512) {
+      float g = 0.0f;
+      if (gj < b) g = pair_grad(S[li * b + gj], row_offset + li, gj, si, sid_cols[gj], lse, 1.0f, gpos);
+      grow[gj] = (f16_t)(g * gscale);
+      gtot += g;
+    }
+    __syncthreads();
+    for (int pass = 0; pass * 512 < H2; ++pass) {
+      const int n = pass * 512 + tid;
+      if (n < H2) {
+        float a = 0.0f;
+        for (int64_t jb = 0; jb < JB; ++jb) {
+          const unsigned w = bitsN[(li * JB + jb) * H2 + n];
+          const f16x8v* gp = reinterpret_cast<const f16x8v*>(grow + jb * 32);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const f16x8v l = lut[(w >> (8 * q)) & 255u];
+            const f16x8v g8 = gp[q];
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              a = __builtin_amdgcn_fdot2(f16x2{l[2 * e], l[2 * e + 1]}, f16x2{g8[2 * e], g8[2 * e + 1]}, a, false);
+          }
+        }
+        macc[pass & 1] += a;
+      }
+    }
+  }
+  const float unscale = go / gscale;
+  for (int pass = 0; pass * 512 < H2 && pass < 2; ++pass) {
+    const int n = pass * 512 + tid;
+    if (n < H2) mslab[(int64_t)blockIdx.x * H2 + n] = macc[pass] * unscale;
+  }
+  gtot = wave_sum(gtot) * go;
+  if ((tid & 63) == 0) red[tid >> 6] = gtot;
+  __syncthreads();
+  if (tid == 0) {
+    float t = 0.0f;
+    for (int w = 0; w < 8; ++w) t += red[w];
+    gsum[blockIdx.x] = t;
+  }
+}
+
 // ================================================================================================= dU / dV kernel, round 4
 // concat_bwd_duv_kernel (mi_concat_bwd.h) spent 58 % of its wave cycles parked at waits (profiles/r3_concat_sq_counters.txt,
 // SQ_WAIT_ANY): four workgroup barriers per 8-column step (g and -V staged through LDS, a two-phase cross-wave sum of the
