@@ -95,7 +95,11 @@ static ConcatPlan plan_concat(Workspace& ws, int64_t br, int64_t b, int64_t h1, 
     if (rps < 16) rps = 16;
     p.rows_per_dsplit = (int)rps;
     p.n_dsplit = (int)((br + rps - 1) / rps);
-    int64_t rpm = (br + 1023) / 1024;
+    // row slices of the db2 launch: 1,024; the fp16 kernel measured 0.543 / 0.503 / 0.478 ms with 1,024 / 2,048 / 4,096
+    // (the finish kernel then 0.058 / 0.061 / 0.068).  MI_DB2_SPLITS: A/B knob.
+    static const int64_t db2_env = getenv("MI_DB2_SPLITS") ? atoll(getenv("MI_DB2_SPLITS")) : 0;
+    const int64_t db2_splits = db2_env > 0 ? db2_env : (precision == MI_PREC_F16 ? 2048 : 1024);
+    int64_t rpm = (br + db2_splits - 1) / db2_splits;
     p.rows_per_msplit = (int)rpm;
     p.n_msplit = (int)((br + rpm - 1) / rpm);
     if (op16) p.w2wp = ws.take<bf16_t>((precision == MI_PREC_F16X3 ? 2 : 1) * h1 * h2);  // F16X3: hi and lo parts
