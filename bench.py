@@ -391,6 +391,10 @@ PMC_KERNEL_OF = {
                               "f16x3": r"concat_bwd_duv3_kernel(<_Float16, float|IDF16_f)"},
     "concat_bwd_dw2_kernel": {"bf16": r"concat_bwd_dw2_kernel(<__bf16|IDF16b)", "f16": r"concat_bwd_dw2_f16_kernel",
                               "f16x3": r"concat_bwd_dw2_kernel(<_Float16|IDF16_)"},
+    # fp8 mode (B = 8192, d = 1024): regular expressions; the (kernel, grid) keys of the PMC file keep the shapes apart
+    "fp8 mode dT = G Y | dY = G^T T": {"fp8": r"gemm_bf16_big_kernel<mi::EpiScaled<mi::EpiStoreMulti>.*grid=\(?(65536|131072)"},
+    "fp8 G": {"fp8": r"gemm_bf16_big_kernel<mi::EpiScaled<mi::EpiGradScore2>, true>"},
+    "fp8 score+LSE": {"fp8": r"gemm_bf16_big_kernel<mi::EpiScaled<mi::EpiScoreLse2>, true>"},
 }
 
 
@@ -410,7 +414,8 @@ def measured_counters(name, b, d, mode="bf16"):
     fingerprint differs from the sources of this build (a stale pass would silently describe other kernels), and only
     accepts the configuration those passes ran (B=4096, d=512, one GPU)."""
     # (the PMC passes run bench.py's defaults: the headline at d = 512, the concat-MLP leg at d = 768)
-    if name not in PMC_KERNEL_OF or (b, d) != ((4096, 768) if name.startswith("concat") else (4096, 512)):
+    shape = (4096, 768) if name.startswith("concat") else ((8192, 1024) if name.startswith("fp8") else (4096, 512))
+    if name not in PMC_KERNEL_OF or (b, d) != shape:
         return None
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
     if not files:
@@ -428,11 +433,14 @@ def measured_counters(name, b, d, mode="bf16"):
     want = want.get(mode) if isinstance(want, dict) else re.escape(want)
     if not want:
         return None
-    for key, val in doc.get("kernels", {}).items():
-        if re.search(want, key):
-            return {"bytes": round(val["total_bytes"]), "fetch": round(val["fetch_bytes"]), "write": round(val["write_bytes"]),
-                    "mfma_busy_frac": val.get("mfma_busy_frac"), "source": src, "commit": doc.get("commit")}
-    return None
+    # several (kernel, grid) entries may match (the separable leg at B = 256 runs the same kernels as the headline): the
+    # configurations this function accepts are the largest launches of their kernels in the passes
+    hits = [val for key, val in doc.get("kernels", {}).items() if re.search(want, key)]
+    if not hits:
+        return None
+    val = max(hits, key=lambda v: v["total_bytes"])
+    return {"bytes": round(val["total_bytes"]), "fetch": round(val["fetch_bytes"]), "write": round(val["write_bytes"]),
+            "mfma_busy_frac": val.get("mfma_busy_frac"), "source": src, "commit": doc.get("commit")}
 
 
 def roofline_of(kernels, br, b, d, precision):
@@ -476,8 +484,13 @@ def fp8_roofline(kernels, b, d):
         return {"kernel": name, "bound": "hbm", "achieved": None, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": None,
                 "traffic": None, "avg_us": round(k["ms_avg"] * 1e3, 2)}
     achieved = fl / (k["ms_avg"] * 1e-3) / 1e12
+    c = measured_counters(name, b, d, "fp8")
+    ok = c is not None and not c.get("stale")
     return {"kernel": name, "bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
-            "frac": round(achieved / peak, 4), "traffic": None, "avg_us": round(k["ms_avg"] * 1e3, 2),
+            "frac": round(achieved / peak, 4), "traffic": c["bytes"] if ok else None,
+            "hbm_gbs": round(c["bytes"] / (k["ms_avg"] * 1e-3) / 1e9, 1) if ok else None, "hbm_peak_gbs": PEAK_HBM_GBS,
+            "mfma_busy_frac": c.get("mfma_busy_frac") if ok else None, "counters": c,
+            "avg_us": round(k["ms_avg"] * 1e3, 2),
             "flops_per_launch": fl, "operands": "fp8 e4m3" if fp8_products else "bf16"}
 
 

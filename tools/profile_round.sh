@@ -17,7 +17,8 @@ BENCH="python3 $REPO/bench.py --graph off --steps 20 --warmup 5 --clock-warmup-m
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o stats -- $BENCH > "$OUT/bench.log" 2>&1 || exit 1
 grep "^{\"metric\"" "$OUT/bench.log" | tail -1 > "$OUT/${TAG}_bench_line.json"
 cp "$(find "$OUT/stats" -name '*kernel_stats.csv' | head -1)" "$OUT/${TAG}_bench_kernel_stats.csv"
-SHORT="python3 $REPO/bench.py --graph off --steps 5 --warmup 2 --clock-warmup-ms 0 --profile-steps 1 --secondary-steps 2 --no-cpu-baseline --no-parity-mode --no-fp8 --timed-iters 50"
+# (the counter passes include the fp8 leg -- B = 8192, d = 1024 -- so that fp8_mode.roofline gets its bytes too)
+SHORT="python3 $REPO/bench.py --graph off --steps 5 --warmup 2 --clock-warmup-ms 0 --profile-steps 1 --secondary-steps 2 --no-cpu-baseline --no-parity-mode --timed-iters 50"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/fetch" -o fetch -- $SHORT > "$OUT/fetch.log" 2>&1 || exit 1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/write" -o write -- $SHORT > "$OUT/write.log" 2>&1 || exit 1
 # matrix-pipe utilisation: SQ_VALU_MFMA_BUSY_CYCLES counts 32 per v_mfma_f32_32x32x16_bf16 (summed over all SIMDs);
