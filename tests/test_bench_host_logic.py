@@ -24,6 +24,10 @@ def test_committed_pmc_pass_belongs_to_these_sources():
     if c.get("stale"):
         pytest.skip("the committed PMC pass predates the kernel sources: re-run tools/profile_round.sh before the round ends")
     assert abs(c["bytes"] - (c["fetch"] + c["write"])) <= 2 and 0.0 < c["mfma_busy_frac"] < 1.0  # (each is rounded)
+    # the separable leg at B = 256 runs the same kernel in the same passes: the lookup must take the headline's launch
+    assert 90e6 < c["bytes"] < 130e6 and c["mfma_busy_frac"] > 0.3
+    f8 = bench.measured_counters("fp8 mode dT = G Y | dY = G^T T", 8192, 1024, "fp8")
+    assert f8 and not f8.get("stale") and f8["bytes"] > 400e6 and 0.3 < f8["mfma_busy_frac"] < 0.9
     assert bench.measured_counters("bilinear fused S | P Y | P^T T", 2048, 512) is None  # only the profiled configuration
 
 
